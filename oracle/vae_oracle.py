@@ -1,0 +1,522 @@
+"""CPU oracle for the conv-VAE training hot path of jbthejedi/vae.
+
+TEST INFRASTRUCTURE ONLY.  Nothing in the product package (vae_amd/) may import
+this file; it is used by tests/, by __graft_entry__.smoke() and by the
+cpu_baseline leg of bench.py as the checker / the timed CPU baseline.
+
+It restates, in plain functional fp32 PyTorch on the CPU, exactly what the
+reference computes on the path
+
+    VAEConv.forward  -> (recons, mu, logvar)        vae/models/vae.py:101-105
+    vae_loss                                        vae/training/train.py:44-51
+    train-step body                                 vae/training/train.py:327-339
+
+Parity is pinned by tests/golden/*.npz, which oracle/make_fixtures.py generated
+by importing the reference classes themselves in the build container (the
+reference has no tests or golden vectors of its own).
+
+The counter-based RNG (Philox4x32-10 and the integer/float transforms built on
+it) is restated here in numpy; it is pinned by the Random123 known-answer
+vectors (tests/test_oracle_philox.py).
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-5          # nn.BatchNorm2d default, vae/models/vae.py:130
+BN_MOMENTUM = 0.1      # nn.BatchNorm2d default
+
+ENC_CHANNELS = (64, 128, 256, 256)   # vae/models/vae.py:34-44
+
+
+# ----------------------------------------------------------------------------
+# Parameter inventory (vae/models/vae.py:23-86).  Order == state_dict order.
+# ----------------------------------------------------------------------------
+def state_shapes(in_channels=3, out_channels=3, latent_dims=128, image_size=32):
+    """Ordered {name: shape} of the 85-entry state_dict of VAEConv."""
+    s = OrderedDict()
+    ci = in_channels
+    for i, co in enumerate(ENC_CHANNELS, start=1):
+        for j, cin in ((0, ci), (3, co)):
+            s[f"conv{i}.net.{j}.weight"] = (co, cin, 3, 3)
+            s[f"conv{i}.net.{j}.bias"] = (co,)
+            b = j + 1
+            s[f"conv{i}.net.{b}.weight"] = (co,)
+            s[f"conv{i}.net.{b}.bias"] = (co,)
+            s[f"conv{i}.net.{b}.running_mean"] = (co,)
+            s[f"conv{i}.net.{b}.running_var"] = (co,)
+            s[f"conv{i}.net.{b}.num_batches_tracked"] = ()
+        ci = co
+    hw = image_size // 8                      # three MaxPool2d(2), vae.py:35-41
+    flat = 256 * hw * hw
+    s["fc_mu.weight"] = (latent_dims, flat)
+    s["fc_mu.bias"] = (latent_dims,)
+    s["fc_logvar.weight"] = (latent_dims, flat)
+    s["fc_logvar.bias"] = (latent_dims,)
+    s["fc_up.weight"] = (flat, latent_dims)
+    s["fc_up.bias"] = (flat,)
+    for name, bn, cin, co in (("up3", "bn3", 256, 128), ("up2", "bn2", 128, 64),
+                              ("up1", "bn1", 64, 64)):
+        s[f"{name}.weight"] = (cin, co, 2, 2)  # ConvTranspose2d is [Cin, Cout, kh, kw]
+        s[f"{name}.bias"] = (co,)
+        s[f"{bn}.weight"] = (co,)
+        s[f"{bn}.bias"] = (co,)
+        s[f"{bn}.running_mean"] = (co,)
+        s[f"{bn}.running_var"] = (co,)
+        s[f"{bn}.num_batches_tracked"] = ()
+    s["head.weight"] = (out_channels, 64, 1, 1)
+    s["head.bias"] = (out_channels,)
+    return s
+
+
+def is_param(name: str) -> bool:
+    return not (name.endswith("running_mean") or name.endswith("running_var")
+                or name.endswith("num_batches_tracked"))
+
+
+def _uniform(shape, bound):
+    return torch.empty(shape, dtype=torch.float32).uniform_(-bound, bound)
+
+
+def construct_state(in_channels=3, out_channels=3, latent_dims=128, p_dropout=0.1,
+                    image_size=32):
+    """Restates VAEConv.__init__ (vae/models/vae.py:23-86) including its side
+    effects, consuming torch's global CPU generator in the same order, so that
+    ``torch.manual_seed(s); construct_state(...)`` equals
+    ``torch.manual_seed(s); VAEConv(...).state_dict()``.
+
+    * Conv2d / Linear / ConvTranspose2d default init: weight and bias both
+      U(-1/sqrt(fan_in), 1/sqrt(fan_in)), fan_in = weight.size(1) * kh * kw
+      (for ConvTranspose2d that is Cout*kh*kw).
+    * the train-mode dummy forward of _get_flattened_dims (vae.py:78-86) draws
+      one Bernoulli(1-p) mask per DoubleConv (when p > 0) and moves every
+      encoder BatchNorm's running stats one step (num_batches_tracked = 1,
+      running_var = 0.9, running_mean = 0.1 * batch mean).
+    * xavier_uniform_(gain=0.1) on fc_mu / fc_logvar weights (vae.py:60-61).
+    """
+    shapes = state_shapes(in_channels, out_channels, latent_dims, image_size)
+    sd = OrderedDict()
+
+    def conv_like(wname, bname):
+        shp = shapes[wname]
+        fan_in = shp[1] * (shp[2] * shp[3] if len(shp) == 4 else 1)
+        bound = 1.0 / math.sqrt(fan_in)
+        sd[wname] = _uniform(shp, bound)
+        sd[bname] = _uniform(shapes[bname], bound)
+
+    def bn(prefix, c):
+        sd[f"{prefix}.weight"] = torch.ones(c)
+        sd[f"{prefix}.bias"] = torch.zeros(c)
+        sd[f"{prefix}.running_mean"] = torch.zeros(c)
+        sd[f"{prefix}.running_var"] = torch.ones(c)
+        sd[f"{prefix}.num_batches_tracked"] = torch.tensor(0, dtype=torch.int64)
+
+    for i, co in enumerate(ENC_CHANNELS, start=1):
+        conv_like(f"conv{i}.net.0.weight", f"conv{i}.net.0.bias")
+        bn(f"conv{i}.net.1", co)
+        conv_like(f"conv{i}.net.3.weight", f"conv{i}.net.3.bias")
+        bn(f"conv{i}.net.4", co)
+
+    # dummy forward on zeros(1, C, S, S) in train mode (vae.py:78-86).  The batch
+    # variance is ~0 there, so every BatchNorm multiplies the rounding noise of
+    # (x - mean) by rsqrt(1e-5) = 316 and the deeper running means are set by that
+    # noise; it is reproduced only by running the very same ATen ops in the same
+    # order, which is what this block does (F.batch_norm / F.dropout, not the
+    # explicit formulas used elsewhere in this file).
+    with torch.no_grad():
+        x = torch.zeros(1, in_channels, image_size, image_size)
+        for i, co in enumerate(ENC_CHANNELS, start=1):
+            for j in (0, 3):
+                b = f"conv{i}.net.{j + 1}"
+                x = F.conv2d(x, sd[f"conv{i}.net.{j}.weight"], sd[f"conv{i}.net.{j}.bias"], padding=1)
+                x = F.batch_norm(x, sd[f"{b}.running_mean"], sd[f"{b}.running_var"],
+                                 sd[f"{b}.weight"], sd[f"{b}.bias"], True, BN_MOMENTUM, BN_EPS)
+                sd[f"{b}.num_batches_tracked"] = torch.tensor(1, dtype=torch.int64)
+                x = torch.relu_(x)
+            x = F.dropout(x, p_dropout, True)     # draws the Bernoulli mask when p > 0
+            if i <= 3:
+                x = F.max_pool2d(x, 2)
+
+    for name in ("fc_mu", "fc_logvar"):
+        conv_like(f"{name}.weight", f"{name}.bias")
+    for name in ("fc_mu", "fc_logvar"):
+        shp = shapes[f"{name}.weight"]
+        a = 0.1 * math.sqrt(6.0 / (shp[0] + shp[1]))
+        sd[f"{name}.weight"] = _uniform(shp, a)
+    conv_like("fc_up.weight", "fc_up.bias")
+    for name, b, co in (("up3", "bn3", 128), ("up2", "bn2", 64), ("up1", "bn1", 64)):
+        conv_like(f"{name}.weight", f"{name}.bias")
+        bn(b, co)
+    conv_like("head.weight", "head.bias")
+    # re-order to state_dict order
+    return OrderedDict((k, sd[k]) for k in shapes)
+
+
+# ----------------------------------------------------------------------------
+# Layers
+# ----------------------------------------------------------------------------
+def batch_norm(x, gamma, beta, running_mean, running_var, train: bool,
+               stats_out: Optional[dict] = None, prefix: str = ""):
+    """nn.BatchNorm2d forward (vae/models/vae.py:130,134,65,68,71).
+
+    train: normalise with the batch mean / biased variance over (N,H,W); the
+    running stats move by momentum 0.1 with the UNBIASED variance.
+    eval: normalise with the running stats.  New running stats are written to
+    ``stats_out`` (the inputs are not modified).
+    """
+    if train:
+        n = x.numel() // x.shape[1]
+        mean = x.mean(dim=(0, 2, 3))
+        var = x.var(dim=(0, 2, 3), unbiased=False)
+        if stats_out is not None:
+            with torch.no_grad():
+                unb = var * (n / max(n - 1, 1))
+                stats_out[f"{prefix}.running_mean"] = (1 - BN_MOMENTUM) * running_mean + BN_MOMENTUM * mean
+                stats_out[f"{prefix}.running_var"] = (1 - BN_MOMENTUM) * running_var + BN_MOMENTUM * unb
+    else:
+        mean, var = running_mean, running_var
+    xhat = (x - mean[None, :, None, None]) * torch.rsqrt(var + BN_EPS)[None, :, None, None]
+    return xhat * gamma[None, :, None, None] + beta[None, :, None, None]
+
+
+def dropout(x, p: float, train: bool, mask: Optional[torch.Tensor]):
+    """nn.Dropout (vae/models/vae.py:137): train -> x * mask / (1-p); eval -> x.
+    ``mask`` is the injected keep-mask (1 = keep)."""
+    if not train or p == 0.0:
+        return x
+    assert mask is not None, "train-mode dropout needs an injected keep-mask"
+    return x * mask.to(x.dtype) / (1.0 - p)
+
+
+def double_conv(x, sd, prefix, train, p_dropout, mask, stats_out=None):
+    """DoubleConv.forward (vae/models/vae.py:125-141)."""
+    for j in (0, 3):
+        x = F.conv2d(x, sd[f"{prefix}.net.{j}.weight"], sd[f"{prefix}.net.{j}.bias"], padding=1)
+        b = f"{prefix}.net.{j + 1}"
+        x = batch_norm(x, sd[f"{b}.weight"], sd[f"{b}.bias"], sd[f"{b}.running_mean"],
+                       sd[f"{b}.running_var"], train, stats_out, b)
+        x = torch.relu(x)
+    return dropout(x, p_dropout, train, mask)
+
+
+def encode(x, sd, train=True, p_dropout=0.0, masks=None, stats_out=None):
+    """VAEConv.encode (vae/models/vae.py:89-98) -> (mu, logvar)."""
+    masks = masks or [None] * 4
+    for i in range(1, 5):
+        x = double_conv(x, sd, f"conv{i}", train, p_dropout, masks[i - 1], stats_out)
+        if i <= 3:
+            x = F.max_pool2d(x, 2)
+    x = torch.flatten(x, start_dim=1)
+    mu = F.linear(x, sd["fc_mu.weight"], sd["fc_mu.bias"])
+    logvar = F.linear(x, sd["fc_logvar.weight"], sd["fc_logvar.bias"])
+    return mu, logvar
+
+
+def reparameterize(mu, logvar, eps):
+    """VAEConv.reparameterize (vae/models/vae.py:108-111) with eps injected."""
+    return mu + torch.exp(0.5 * logvar) * eps
+
+
+def decode(z, sd, train=True, stats_out=None):
+    """VAEConv.decode (vae/models/vae.py:114-122)."""
+    flat = sd["fc_up.weight"].shape[0]
+    hw = int(round(math.sqrt(flat // 256)))
+    x = torch.tanh(F.linear(z, sd["fc_up.weight"], sd["fc_up.bias"])).view(-1, 256, hw, hw)
+    for up, bn in (("up3", "bn3"), ("up2", "bn2"), ("up1", "bn1")):
+        x = F.conv_transpose2d(x, sd[f"{up}.weight"], sd[f"{up}.bias"], stride=2)
+        x = batch_norm(x, sd[f"{bn}.weight"], sd[f"{bn}.bias"], sd[f"{bn}.running_mean"],
+                       sd[f"{bn}.running_var"], train, stats_out, bn)
+        x = torch.relu(x)
+    return torch.sigmoid(F.conv2d(x, sd["head.weight"], sd["head.bias"]))
+
+
+def forward(x, sd, eps, train=True, p_dropout=0.0, masks=None, stats_out=None):
+    """VAEConv.forward (vae/models/vae.py:101-105) -> (recons, mu, logvar)."""
+    mu, logvar = encode(x, sd, train, p_dropout, masks, stats_out)
+    z = reparameterize(mu, logvar, eps)
+    return decode(z, sd, train, stats_out), mu, logvar
+
+
+# ----------------------------------------------------------------------------
+# Loss (vae/training/train.py:44-55 and the draft variants)
+# ----------------------------------------------------------------------------
+RECON_KINDS = ("l1", "mse", "bce", "bce_logits")
+
+
+def recon_loss_sum(recon, target, kind: str):
+    """reduction='sum' reconstruction term.
+    l1  : F.l1_loss                                   vae/training/train.py:55
+    mse : F.mse_loss                                  vae/practice/vae_conv.py:160-165
+    bce : F.binary_cross_entropy (log clamped >= -100) vae/bak/vae_conv.py:183-190
+    bce_logits : F.binary_cross_entropy_with_logits on logits clamped to
+          [-10, 10]                                   vae/practice/vae_conv.py:146-151
+    """
+    if kind == "l1":
+        return (recon - target).abs().sum()
+    if kind == "mse":
+        return ((recon - target) ** 2).sum()
+    if kind == "bce":
+        lr = torch.clamp(torch.log(recon), min=-100.0)
+        l1r = torch.clamp(torch.log(1.0 - recon), min=-100.0)
+        return -(target * lr + (1.0 - target) * l1r).sum()
+    if kind == "bce_logits":
+        xl = recon.clamp(-10.0, 10.0)
+        # max(x,0) - x*t + log(1 + exp(-|x|))
+        return (xl.clamp(min=0) - xl * target + torch.log1p(torch.exp(-xl.abs()))).sum()
+    raise ValueError(kind)
+
+
+def kl_sum(mu, logvar):
+    """-0.5 * sum(1 + logvar - mu^2 - exp(logvar))   vae/training/train.py:47"""
+    return -0.5 * torch.sum(1 + logvar - mu.pow(2) - logvar.exp())
+
+
+def vae_loss(recon, target, mu, logvar, kind="l1", kl_weight=1.0):
+    """(recon_sum + kl_weight * KL) / N  (percep_weight = 0)  vae/training/train.py:50"""
+    return (recon_loss_sum(recon, target, kind) + kl_weight * kl_sum(mu, logvar)) / recon.size(0)
+
+
+# ----------------------------------------------------------------------------
+# Train step (vae/training/train.py:327-339)
+# ----------------------------------------------------------------------------
+def clip_grad_norm(grads: Dict[str, torch.Tensor], max_norm=1.0):
+    """torch.nn.utils.clip_grad_norm_ (train.py:336): global L2 norm over all
+    grads, coefficient max_norm/(norm+1e-6) clamped to <= 1.  Returns the
+    pre-clip norm; grads are scaled in place."""
+    total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())).float()
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    for g in grads.values():
+        g.mul_(coef)
+    return total
+
+
+def adamw_step(params, grads, exp_avg, exp_avg_sq, step: int, lr=1e-4, betas=(0.9, 0.999),
+               eps=1e-8, weight_decay=0.01):
+    """torch.optim.AdamW defaults (train.py:310), single step ``step`` (1-based)."""
+    b1, b2 = betas
+    bc1 = 1 - b1 ** step
+    bc2 = 1 - b2 ** step
+    for k, p in params.items():
+        g = grads[k]
+        p.mul_(1 - lr * weight_decay)
+        exp_avg[k].mul_(b1).add_(g, alpha=1 - b1)
+        exp_avg_sq[k].mul_(b2).addcmul_(g, g, value=1 - b2)
+        denom = (exp_avg_sq[k].sqrt() / math.sqrt(bc2)).add_(eps)
+        p.addcdiv_(exp_avg[k], denom, value=-(lr / bc1))
+
+
+def loss_and_grads(x, sd, eps, kind="l1", kl_weight=1.0, train=True, p_dropout=0.0, masks=None):
+    """forward + loss + backward.  Returns (loss, recon, mu, logvar, grads, new_stats)."""
+    params = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items() if is_param(k)}
+    full = dict(sd)
+    full.update(params)
+    stats = {}
+    recon, mu, logvar = forward(x, full, eps, train, p_dropout, masks, stats)
+    loss = vae_loss(recon, x, mu, logvar, kind, kl_weight)
+    gl = torch.autograd.grad(loss, list(params.values()), allow_unused=True)
+    grads = {k: (g if g is not None else torch.zeros_like(params[k]))
+             for k, g in zip(params.keys(), gl)}
+    return loss.detach(), recon.detach(), mu.detach(), logvar.detach(), grads, stats
+
+
+def train_step(x, sd, opt_state, eps, kind="l1", kl_weight=1.0, p_dropout=0.0, masks=None,
+               lr=1e-4, max_norm=1.0):
+    """One reference train step on state ``sd`` (updated in place).
+    opt_state = {"step": int, "exp_avg": {...}, "exp_avg_sq": {...}}."""
+    loss, recon, mu, logvar, grads, stats = loss_and_grads(x, sd, eps, kind, kl_weight, True,
+                                                           p_dropout, masks)
+    gnorm = clip_grad_norm(grads, max_norm)
+    opt_state["step"] += 1
+    params = {k: v for k, v in sd.items() if is_param(k)}
+    with torch.no_grad():
+        adamw_step(params, grads, opt_state["exp_avg"], opt_state["exp_avg_sq"], opt_state["step"], lr)
+        for k, v in stats.items():
+            sd[k] = v
+        for k in sd:
+            if k.endswith("num_batches_tracked"):
+                sd[k] = sd[k] + 1
+    return loss, gnorm
+
+
+def new_opt_state(sd):
+    return {"step": 0,
+            "exp_avg": {k: torch.zeros_like(v) for k, v in sd.items() if is_param(k)},
+            "exp_avg_sq": {k: torch.zeros_like(v) for k, v in sd.items() if is_param(k)}}
+
+
+# ----------------------------------------------------------------------------
+# Counter-based RNG: Philox4x32-10 (Salmon et al., SC'11; Random123 v1.14).
+# The reference draws eps with torch.randn_like (vae.py:110) and dropout masks
+# with nn.Dropout (vae.py:137) from torch's global generator; the MI355X build
+# replaces those with explicit Philox streams whose definition is below.
+# ----------------------------------------------------------------------------
+PHILOX_M0 = np.uint64(0xD2511F53)
+PHILOX_M1 = np.uint64(0xCD9E8D57)
+PHILOX_W0 = np.uint32(0x9E3779B9)
+PHILOX_W1 = np.uint32(0xBB67AE85)
+
+STREAM_DROPOUT = (0, 1, 2, 3)   # one stream per DoubleConv
+STREAM_EPS = 4
+
+
+def philox4x32_10(ctr: np.ndarray, key: np.ndarray) -> np.ndarray:
+    """ctr: [..., 4] uint32, key: [..., 2] uint32 (broadcastable) -> [..., 4] uint32."""
+    c = [ctr[..., i].astype(np.uint32) for i in range(4)]
+    k0 = np.broadcast_to(key[..., 0].astype(np.uint32), c[0].shape).copy()
+    k1 = np.broadcast_to(key[..., 1].astype(np.uint32), c[0].shape).copy()
+    mask32 = np.uint64(0xFFFFFFFF)
+    with np.errstate(over="ignore"):
+        for r in range(10):
+            p0 = PHILOX_M0 * c[0].astype(np.uint64)
+            p1 = PHILOX_M1 * c[2].astype(np.uint64)
+            hi0 = (p0 >> np.uint64(32)).astype(np.uint32)
+            lo0 = (p0 & mask32).astype(np.uint32)
+            hi1 = (p1 >> np.uint64(32)).astype(np.uint32)
+            lo1 = (p1 & mask32).astype(np.uint32)
+            c = [hi1 ^ c[1] ^ k0, lo1, hi0 ^ c[3] ^ k1, lo0]
+            k0 = (k0 + PHILOX_W0).astype(np.uint32)
+            k1 = (k1 + PHILOX_W1).astype(np.uint32)
+    return np.stack(c, axis=-1)
+
+
+def philox_bits(n: int, seed: int, stream: int, step: int, rank: int = 0) -> np.ndarray:
+    """The uint32 stream element i (0 <= i < n) of a (seed, stream, step, rank)
+    draw: word i%4 of philox(ctr = {i/4, step, stream, rank}, key = {seed_lo, seed_hi})."""
+    nb = (n + 3) // 4
+    ctr = np.zeros((nb, 4), dtype=np.uint32)
+    ctr[:, 0] = np.arange(nb, dtype=np.uint64).astype(np.uint32)
+    ctr[:, 1] = np.uint32(step & 0xFFFFFFFF)
+    ctr[:, 2] = np.uint32(stream)
+    ctr[:, 3] = np.uint32(rank)
+    key = np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], dtype=np.uint32)
+    return philox4x32_10(ctr, key[None, :]).reshape(-1)[:n]
+
+
+def dropout_threshold(p: float) -> int:
+    """keep iff (bits >> 8) >= ceil(p * 2^24)  (P(keep) = 1 - thr/2^24)."""
+    return int(math.ceil(p * 16777216.0))
+
+
+def philox_keep_mask(n: int, p: float, seed: int, stream: int, step: int, rank: int = 0) -> np.ndarray:
+    bits = philox_bits(n, seed, stream, step, rank)
+    return ((bits >> np.uint32(8)) >= np.uint32(dropout_threshold(p))).astype(np.uint8)
+
+
+# fp32-only Box-Muller built from individually rounded +,*,/ and sqrt (no fma,
+# no libm), so that the HIP kernel and this restatement agree bit for bit.
+_F = np.float32
+_LN2 = _F(0.69314718055994530942)
+_SQRT2 = _F(1.41421356237309504880)
+_HALF_PI = _F(1.57079632679489661923)
+# atanh-series coefficients 2/(2k+1)
+_LOG_C = [_F(2.0 / (2 * k + 1)) for k in range(0, 6)]
+# sin(x), cos(x) Taylor coefficients on |x| <= pi/4
+_SIN_C = [_F(-1.0 / 6), _F(1.0 / 120), _F(-1.0 / 5040), _F(1.0 / 362880)]
+_COS_C = [_F(-0.5), _F(1.0 / 24), _F(-1.0 / 720), _F(1.0 / 40320), _F(-1.0 / 3628800)]
+
+
+def _log_f32(u: np.ndarray) -> np.ndarray:
+    """ln(u) for normal positive fp32 u, fp32 ops only."""
+    bits = u.view(np.uint32)
+    e = ((bits >> np.uint32(23)) & np.uint32(0xFF)).astype(np.int32) - 127
+    m = ((bits & np.uint32(0x007FFFFF)) | np.uint32(0x3F800000)).view(np.float32)  # [1,2)
+    big = m > _SQRT2
+    m = np.where(big, m * _F(0.5), m).astype(np.float32)
+    e = np.where(big, e + 1, e)
+    f = (m - _F(1.0)).astype(np.float32)
+    s = (f / (_F(2.0) + f)).astype(np.float32)
+    s2 = (s * s).astype(np.float32)
+    poly = _LOG_C[5]
+    for k in (4, 3, 2, 1, 0):
+        poly = ((poly * s2).astype(np.float32) + _LOG_C[k]).astype(np.float32)
+    lm = (poly * s).astype(np.float32)
+    return ((e.astype(np.float32) * _LN2).astype(np.float32) + lm).astype(np.float32)
+
+
+def _sincos_quarter(r: np.ndarray):
+    """sin and cos of (pi/2)*r for r in [0,1), fp32 ops only."""
+    swap = r > _F(0.5)
+    rr = np.where(swap, (_F(1.0) - r).astype(np.float32), r).astype(np.float32)
+    x = (rr * _HALF_PI).astype(np.float32)
+    x2 = (x * x).astype(np.float32)
+    ps = _SIN_C[3]
+    for k in (2, 1, 0):
+        ps = ((ps * x2).astype(np.float32) + _SIN_C[k]).astype(np.float32)
+    sn = (x + ((x * x2).astype(np.float32) * ps).astype(np.float32)).astype(np.float32)
+    pc = _COS_C[4]
+    for k in (3, 2, 1, 0):
+        pc = ((pc * x2).astype(np.float32) + _COS_C[k]).astype(np.float32)
+    cs = (_F(1.0) + (x2 * pc).astype(np.float32)).astype(np.float32)
+    return np.where(swap, cs, sn).astype(np.float32), np.where(swap, sn, cs).astype(np.float32)
+
+
+def normal_pair_from_bits(b0: np.ndarray, b1: np.ndarray):
+    """Box-Muller: u1 = ((b0>>8)+1)*2^-24 in (0,1], u2 = (b1>>8)*2^-24 in [0,1);
+    (z0, z1) = sqrt(-2 ln u1) * (cos, sin)(2 pi u2)."""
+    u1 = ((b0 >> np.uint32(8)).astype(np.float32) + _F(1.0)) * _F(2.0 ** -24)
+    u1 = u1.astype(np.float32)
+    t = (b1 >> np.uint32(8))
+    quad = (t >> np.uint32(22)).astype(np.int32)                  # 2 top bits of 24
+    r = ((t & np.uint32(0x3FFFFF)).astype(np.float32) * _F(2.0 ** -22)).astype(np.float32)
+    sn, cs = _sincos_quarter(r)
+    # rotate by quadrant: angle = (quad + r) * pi/2
+    c = np.select([quad == 0, quad == 1, quad == 2], [cs, -sn, -cs], default=sn).astype(np.float32)
+    s = np.select([quad == 0, quad == 1, quad == 2], [sn, cs, -sn], default=-cs).astype(np.float32)
+    rad = np.sqrt((_F(-2.0) * _log_f32(u1)).astype(np.float32)).astype(np.float32)
+    return (rad * c).astype(np.float32), (rad * s).astype(np.float32)
+
+
+def philox_normal(n: int, seed: int, stream: int, step: int, rank: int = 0) -> np.ndarray:
+    """eps element i: words (0,1) of block i/4 give elements 4b, 4b+1; words (2,3) give 4b+2, 4b+3."""
+    nb = (n + 3) // 4
+    bits = philox_bits(nb * 4, seed, stream, step, rank).reshape(nb, 4)
+    z0, z1 = normal_pair_from_bits(bits[:, 0], bits[:, 1])
+    z2, z3 = normal_pair_from_bits(bits[:, 2], bits[:, 3])
+    return np.stack([z0, z1, z2, z3], axis=1).reshape(-1)[:n]
+
+
+# ----------------------------------------------------------------------------
+# Test-input helpers shared by oracle/make_fixtures.py and tests/
+# ----------------------------------------------------------------------------
+def perturb_norm_params(sd, seed: int):
+    """Deterministically move every BatchNorm affine parameter / running stat
+    away from its (1, 0, ~0, ~1) initial value so that parity tests exercise
+    them.  Uses a private generator; the global RNG is untouched."""
+    g = torch.Generator().manual_seed(seed + 1)
+    for k in sd:
+        if k.endswith("num_batches_tracked") or sd[k].dim() != 1:
+            continue
+        is_bn = (".net.1." in k or ".net.4." in k or k.startswith("bn"))
+        if not is_bn:
+            continue
+        n = sd[k].numel()
+        if k.endswith(".weight"):
+            sd[k] = 0.5 + torch.rand(n, generator=g)
+        elif k.endswith(".bias"):
+            sd[k] = 0.4 * torch.rand(n, generator=g) - 0.2
+        elif k.endswith("running_mean"):
+            sd[k] = 0.2 * torch.rand(n, generator=g) - 0.1
+        elif k.endswith("running_var"):
+            sd[k] = 0.5 + torch.rand(n, generator=g)
+    return sd
+
+
+def make_inputs(n, in_channels, image_size, latent_dims, seed):
+    g = torch.Generator().manual_seed(seed + 2)
+    x = torch.rand(n, in_channels, image_size, image_size, generator=g)
+    eps = torch.randn(n, latent_dims, generator=g)
+    return x, eps
+
+
+def tensor_digest(t: torch.Tensor, nsample: int = 256):
+    """(l2 norm, sum, strided samples) of a tensor, for compact golden files."""
+    f = t.detach().reshape(-1).double()
+    stride = max(1, f.numel() // nsample)
+    return (np.array([f.norm().item(), f.sum().item()], dtype=np.float64),
+            f[::stride][:nsample].float().numpy().copy())
