@@ -76,4 +76,13 @@ def test_train_steps():
         assert abs(loss.item() - c.z[f"step{s}/loss"].item()) <= 1e-5 * abs(c.z[f"step{s}/loss"].item())
         assert abs(gn.item() - c.z[f"step{s}/grad_norm"].item()) <= 1e-4 * c.z[f"step{s}/grad_norm"].item()
     for k, v in sd.items():
-        check_digest(c, "final", k, v.float(), rtol=1e-5, atol_scale=1e-7)
+        # biases in front of a train-mode BatchNorm receive pure rounding-noise gradients, which
+        # AdamW normalises to +-lr per step: after `steps` steps they sit anywhere within
+        # steps*lr of their initial value, in the reference as much as here.
+        # The running means of those BatchNorms follow the bias (momentum 0.1 per step).
+        atol = 1e-7
+        if zero_grad_bias(k):
+            atol = steps * 1e-4 * 1.01
+        elif k.endswith("running_mean"):
+            atol = steps * 1e-4 * 0.3
+        check_digest(c, "final", k, v.float(), rtol=1e-5, atol_scale=atol)
