@@ -1,0 +1,105 @@
+/* libvae_hip.so -- C ABI of the MI355X (gfx950) kernels behind the conv-VAE hot path.
+ *
+ * The reference (jbthejedi/vae) has no FFI or operator plug-in interface: its hot path is
+ * plain torch.nn calls.  Each entry point below therefore names the torch call site in the
+ * reference that it replaces (file:line under the reference root).
+ *
+ * Conventions
+ *   - every pointer is a device pointer (tensor.data_ptr()); activations are NHWC bf16 unless
+ *     the name says otherwise; "f32" pointers are float.
+ *   - the library never allocates, frees or keeps a pointer past return; the caller owns all
+ *     outputs and workspaces.  Work is only ENQUEUED on `stream` (a hipStream_t); nothing
+ *     synchronises.
+ *   - return 0 on success; non-zero on a rejected argument or failed launch, with the reason
+ *     in vae_last_error() (thread-local).
+ */
+#ifndef VAE_HIP_H
+#define VAE_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VAE_HIP_VERSION 1
+
+/* reconstruction-term kinds */
+#define VAE_RECON_L1 0          /* F.l1_loss(reduction="sum")                 vae/training/train.py:55        */
+#define VAE_RECON_MSE 1         /* F.mse_loss(reduction="sum")                vae/practice/vae_conv.py:160-165 */
+#define VAE_RECON_BCE 2         /* F.binary_cross_entropy(reduction="sum")    vae/bak/vae_conv.py:183-190     */
+#define VAE_RECON_BCE_LOGITS 3  /* BCE-with-logits on clamp(x,-10,10)         vae/practice/vae_conv.py:146-151 */
+
+/* Philox stream ids: one per DoubleConv dropout (vae/models/vae.py:137) + eps (vae.py:110) */
+#define VAE_STREAM_DROPOUT0 0
+#define VAE_STREAM_EPS 4
+
+/* GEMM epilogues of vae_linear_gemm */
+#define VAE_EPI_BF16 0        /* out bf16 [M][N]                                  */
+#define VAE_EPI_TANH_BF16 1   /* out bf16 = tanh(acc + bias)                      */
+#define VAE_EPI_F32 2         /* out f32 [M][N]                                   */
+#define VAE_EPI_F32_SPLIT 3   /* out f32 [M][N/2] (cols < N/2), out2 f32 [M][N/2] */
+
+int vae_version(void);
+const char* vae_last_error(void);
+
+/* ---- ELBO loss: vae_loss(), vae/training/train.py:44-51 -------------------------------- */
+/* number of workgroups (= length of the `partial` array) the loss kernel uses for n_elems */
+int vae_recon_loss_grid(long n_elems);
+/* recon-term forward + backward in one pass: partial[b] = per-workgroup sum of the `kind` loss,
+ * grad[i] = grad_scale * d loss_i / d recon_i  (grad may be NULL: forward only). */
+int vae_recon_loss_fwd_bwd(const float* recon, const float* target, float* grad, float* partial,
+                           long n_elems, int kind, float grad_scale, void* stream);
+/* out3[0] = (sum(recon_partial) + kl_weight * sum(kl_partial)) * inv_batch   (train.py:50)
+ * out3[1] = recon sum, out3[2] = KL sum */
+int vae_elbo_combine(const float* recon_partial, int n_recon, const float* kl_partial, int n_kl,
+                     float kl_weight, float inv_batch, float* out3, void* stream);
+
+/* ---- reparameterisation + KL: VAEConv.reparameterize, vae/models/vae.py:108-111, and the KL
+ *      term of vae_loss, vae/training/train.py:47 ------------------------------------------ */
+int vae_reparam_grid(long n_elems);
+/* z = mu + exp(0.5 logvar) * eps; eps = eps_in if given, else Philox(seed, step, EPS stream, rank).
+ * kl_partial[b] = per-workgroup share of -0.5*sum(1 + logvar - mu^2 - exp(logvar)).
+ * z_f32 / z_bf16 / eps_out are optional outputs. */
+int vae_reparam_kl_fwd(const float* mu, const float* logvar, const float* eps_in, float* z_f32,
+                       void* z_bf16, float* eps_out, float* kl_partial, long n_elems,
+                       unsigned long long seed, unsigned step, unsigned rank, void* stream);
+/* dmu = dz + dmu_ext + kl_scale*mu ; dlogvar = dz*eps*0.5*exp(0.5 logvar) + dlv_ext
+ *       + kl_scale*0.5*(exp(logvar)-1).  dz, eps_in, dmu_ext, dlv_ext may be NULL.
+ * dcat_bf16 (optional) = [row][dmu(0:L) | dlogvar(L:2L)]. */
+int vae_reparam_kl_bwd(const float* dz, const float* mu, const float* logvar, const float* eps_in,
+                       const float* dmu_ext, const float* dlv_ext, float kl_scale, float* dmu,
+                       float* dlv, void* dcat_bf16, long n_elems, int latent,
+                       unsigned long long seed, unsigned step, unsigned rank, void* stream);
+/* raw streams, for RNG parity checks.  mode 0: uint32 words, 1: fp32 normals, 2: uint8 keep-mask
+ * with drop probability p_drop.  (torch.randn_like vae.py:110 / nn.Dropout vae.py:137) */
+int vae_philox_fill(void* out, long n, int mode, double p_drop, unsigned long long seed,
+                    unsigned step, unsigned stream_id, unsigned rank, void* stream);
+unsigned vae_dropout_threshold(double p_drop);
+
+/* ---- implicit-GEMM layers (bf16 MFMA, fp32 accumulate) ---------------------------------- */
+/* rows of the GEMM M dimension per workgroup: stat_sum / stat_sq hold ceil(M/rows) x N floats */
+int vae_gemm_rows_per_block(void);
+/* nn.Conv2d(Cin, Cout, 3, padding=1) forward, vae/models/vae.py:129,133 -- and, with the
+ * flipped/transposed weight pack, its dgrad.  x [n,H,W,Cin], w_packed [Cout][9][Cin],
+ * y [n,H,W,Cout].  stat_* (optional): per-workgroup per-channel sum / sum of squares of y. */
+int vae_conv3x3_gemm(const void* x, const void* w_packed, const float* bias, void* y,
+                     float* stat_sum, float* stat_sq, int n_img, int H, int W, int Cin, int Cout,
+                     void* stream);
+/* nn.ConvTranspose2d(Cin, Cout, 2, stride=2) forward, vae/models/vae.py:64,67,70.
+ * x [n,H,W,Cin], w_packed [(kh,kw,co)][Cin], y [n,2H,2W,Cout]; stats are per GEMM column
+ * (tap*Cout + co), 4*Cout of them. */
+int vae_convt2x2_fwd_gemm(const void* x, const void* w_packed, const float* bias, void* y,
+                          float* stat_sum, float* stat_sq, int n_img, int H, int W, int Cin,
+                          int Cout, void* stream);
+/* its dgrad: dy [n,2H,2W,Cout], w_packed [Cin][(kh,kw,co)], dx [n,H,W,Cin] */
+int vae_convt2x2_dgrad_gemm(const void* dy, const void* w_packed, void* dx, int n_img, int H,
+                            int W, int Cin, int Cout, void* stream);
+/* nn.Linear forward / dgrad (fc_mu | fc_logvar fused, fc_up), vae/models/vae.py:48-49,63,96-97,116:
+ * out[m][n] = sum_k a[m][k] w[n][k] (+ bias[n]).  K % 64 == 0, or K % 32 == 0 with VAE_EPI_BF16. */
+int vae_linear_gemm(const void* a, const void* w, const float* bias, void* out, void* out2,
+                    float* stat_sum, float* stat_sq, int M, int N, int K, int epilogue,
+                    void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

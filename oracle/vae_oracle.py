@@ -439,6 +439,17 @@ def _log_f32(u: np.ndarray) -> np.ndarray:
     return ((e.astype(np.float32) * _LN2).astype(np.float32) + lm).astype(np.float32)
 
 
+def _sqrt_f32(x: np.ndarray) -> np.ndarray:
+    """sqrt by three Newton steps from an integer first guess, fp32 ops only
+    (each of /, +, * individually rounded; x <= 0 -> 0)."""
+    pos = x > _F(0.0)
+    xs = np.where(pos, x, _F(1.0)).astype(np.float32)
+    y = (np.uint32(0x1FBD1DF5) + (xs.view(np.uint32) >> np.uint32(1))).astype(np.uint32).view(np.float32)
+    for _ in range(3):
+        y = (_F(0.5) * (y + (xs / y).astype(np.float32)).astype(np.float32)).astype(np.float32)
+    return np.where(pos, y, _F(0.0)).astype(np.float32)
+
+
 def _sincos_quarter(r: np.ndarray):
     """sin and cos of (pi/2)*r for r in [0,1), fp32 ops only."""
     swap = r > _F(0.5)
@@ -468,7 +479,7 @@ def normal_pair_from_bits(b0: np.ndarray, b1: np.ndarray):
     # rotate by quadrant: angle = (quad + r) * pi/2
     c = np.select([quad == 0, quad == 1, quad == 2], [cs, -sn, -cs], default=sn).astype(np.float32)
     s = np.select([quad == 0, quad == 1, quad == 2], [sn, cs, -sn], default=-cs).astype(np.float32)
-    rad = np.sqrt((_F(-2.0) * _log_f32(u1)).astype(np.float32)).astype(np.float32)
+    rad = _sqrt_f32((_F(-2.0) * _log_f32(u1)).astype(np.float32))
     return (rad * c).astype(np.float32), (rad * s).astype(np.float32)
 
 

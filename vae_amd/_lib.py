@@ -1,0 +1,74 @@
+"""ctypes binding of libvae_hip.so (the C ABI declared in include/vae_hip.h).
+
+There is no fallback: if the shared library is missing or fails to load, importing the
+kernels raises, and every non-zero return code becomes a RuntimeError carrying
+vae_last_error().
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_float, c_int, c_long, c_uint, c_ulonglong, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvae_hip.so")
+
+P = c_void_p
+
+# name -> (restype, argtypes); restype None means "int status, raise on non-zero"
+SIGNATURES = {
+    "vae_version": (c_int, []),
+    "vae_last_error": (c_char_p, []),
+    "vae_recon_loss_grid": (c_int, [c_long]),
+    "vae_recon_loss_fwd_bwd": (None, [P, P, P, P, c_long, c_int, c_float, P]),
+    "vae_elbo_combine": (None, [P, c_int, P, c_int, c_float, c_float, P, P]),
+    "vae_reparam_grid": (c_int, [c_long]),
+    "vae_reparam_kl_fwd": (None, [P, P, P, P, P, P, P, c_long, c_ulonglong, c_uint, c_uint, P]),
+    "vae_reparam_kl_bwd": (None, [P, P, P, P, P, P, c_float, P, P, P, c_long, c_int, c_ulonglong,
+                                  c_uint, c_uint, P]),
+    "vae_philox_fill": (None, [P, c_long, c_int, c_double, c_ulonglong, c_uint, c_uint, c_uint, P]),
+    "vae_dropout_threshold": (c_uint, [c_double]),
+    "vae_gemm_rows_per_block": (c_int, []),
+    "vae_conv3x3_gemm": (None, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "vae_convt2x2_fwd_gemm": (None, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "vae_convt2x2_dgrad_gemm": (None, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "vae_linear_gemm": (None, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libvae_hip.so once and attach the prototypes.  Raises if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `make -C vae_amd/csrc` "
+            "(or python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype = c_int if res is None else res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def ptr(t):
+    """device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if SIGNATURES[name][0] is None and rc != 0:
+        raise RuntimeError(f"{name} failed ({rc}): {lib.vae_last_error().decode()}")
+    return rc
+
+
+def current_stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

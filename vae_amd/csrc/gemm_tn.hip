@@ -1,0 +1,358 @@
+// bf16 MFMA implicit-GEMM, "TN" form:  out[m][n] = sum_k A[m][k] * B[n][k]  (fp32 accumulate).
+//
+// Both operands are K-contiguous in memory, so every LDS row is a 128-byte (BK=64) or
+// 64-byte (BK=32) run of one operand row and MFMA fragments are plain ds_read_b128.
+// The A side (activations, NHWC) is addressed through a per-row gather, which is what makes
+// the GEMM "implicit":
+//   A_PLAIN        row m = A + m*lda                                   (linear, im2col'd conv1a, convT fwd)
+//   A_CONV3        row m = pixel (img,h,w); K = (tap, c): the tap's neighbour pixel or the
+//                  zero page when it falls in the padding              (3x3 s1 p1 conv fwd and dgrad)
+//   A_CONVT_DGRAD  row m = input pixel (img,i,j); K = (tap, c): output pixel (2i+kh, 2j+kw)
+//                                                                      (ConvTranspose2d k2 s2 dgrad)
+// Tiles are staged global -> LDS with global_load_lds (16 B per lane, no VGPR round trip);
+// the LDS image is lane-linear, the XOR bank swizzle is applied to the per-lane SOURCE chunk
+// and again on the fragment read.  Double-buffered, one barrier per K-step.
+//
+// MFMA orientation: weights are the MFMA "A" operand (rows = output channels) and activations
+// the "B" operand (columns = pixels), so a lane ends up holding 4 CONSECUTIVE channels of one
+// pixel per accumulator -> 8-byte (bf16) / 16-byte (fp32) NHWC stores, and per-channel batch
+// statistics reduce over the 16 lanes that share (lane >> 4).
+#include "common.h"
+#include "../../include/vae_hip.h"
+
+namespace vae {
+
+__device__ __attribute__((aligned(256))) unsigned int g_zero_page[64];
+
+enum { A_PLAIN = 0, A_CONV3 = 1, A_CONVT_DGRAD = 2 };
+enum { E_BF16 = 0, E_CONVT = 1, E_F32_SPLIT = 2, E_TANH_BF16 = 3, E_F32 = 4 };
+
+struct GemmTN {
+    const bf16_t* A;
+    const bf16_t* B;      // [N][K]
+    const float* bias;    // [N] ([Co] for E_CONVT), may be null
+    void* out;
+    void* out2;           // E_F32_SPLIT: second half
+    float* stat_sum;      // [gridM][N] per-workgroup column sums of the stored values, may be null
+    float* stat_sq;
+    int M, N, K;
+    int lda;              // A_PLAIN
+    int H, W, C;          // gather geometry (see above)
+    int ldo;              // output row stride in elements
+    int split;            // E_F32_SPLIT: columns per half
+    int Co;               // E_CONVT: channels per tap
+};
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int BM, int BN, int BK, int WAVES_M, int AMODE, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
+    constexpr int WAVES_N = 4 / WAVES_M;
+    constexpr int TM = BM / WAVES_M, TN = BN / WAVES_N;
+    constexpr int FM = TM / 16, FN = TN / 16;
+    constexpr int ROWB = BK * 2;               // bytes per LDS row
+    constexpr int CH = BK / 8;                 // 16-byte chunks per row
+    constexpr int RPI = 64 / CH;               // rows written by one wave-instruction
+    constexpr int SW = (BK == 64) ? 1 : 2;     // rows per 256-byte bank row = 1 << SW
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
+    constexpr int A_INSTR = BM / RPI / 4, B_INSTR = BN / RPI / 4;
+    static_assert(FM >= 1 && FN >= 1 && A_INSTR >= 1 && B_INSTR >= 1, "tile too small");
+    static_assert(2 * STAGE >= (int)(2 * WAVES_M * BN * sizeof(float)), "stats scratch does not fit");
+
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+
+    // ---- per-lane staging state ------------------------------------------------------
+    const bf16_t* zero = (const bf16_t*)g_zero_page;
+    long a_off[A_INSTR];
+    int a_hw[A_INSTR];
+    bool a_ok[A_INSTR];
+#pragma unroll
+    for (int i = 0; i < A_INSTR; ++i) {
+        const int row = (wave + 4 * i) * RPI + lane / CH;
+        const int chunk = (lane % CH) ^ ((row >> SW) & (CH - 1));
+        const int m = m0 + row;
+        a_ok[i] = m < p.M;
+        a_hw[i] = 0;
+        if (AMODE == A_PLAIN) {
+            a_off[i] = (long)m * p.lda + chunk * 8;
+        } else if (AMODE == A_CONV3) {
+            const int w = m % p.W, t = m / p.W, h = t % p.H, img = t / p.H;
+            a_off[i] = (((long)img * p.H + h) * p.W + w) * p.C + chunk * 8;
+            a_hw[i] = (h << 16) | w;
+        } else {
+            const int j = m % p.W, t = m / p.W, ii = t % p.H, img = t / p.H;
+            a_off[i] = (((long)img * 2 * p.H + 2 * ii) * (2 * p.W) + 2 * j) * p.C + chunk * 8;
+        }
+    }
+    long b_off[B_INSTR];
+    bool b_ok[B_INSTR];
+#pragma unroll
+    for (int i = 0; i < B_INSTR; ++i) {
+        const int row = (wave + 4 * i) * RPI + lane / CH;
+        const int chunk = (lane % CH) ^ ((row >> SW) & (CH - 1));
+        const int n = n0 + row;
+        b_ok[i] = n < p.N;
+        b_off[i] = (long)n * p.K + chunk * 8;
+    }
+    const int cpt = (AMODE == A_PLAIN) ? 1 : p.C / BK;   // K-steps per tap
+
+    auto stage = [&](int buf, int ks) {
+        unsigned char* abase = smem + buf * STAGE;
+        long tap_off = 0;
+        int dh = 0, dw = 0;
+        if (AMODE == A_PLAIN) {
+            tap_off = (long)ks * BK;
+        } else if (AMODE == A_CONV3) {
+            const int tap = ks / cpt, c0 = (ks - tap * cpt) * BK;
+            dh = tap / 3 - 1;
+            dw = tap % 3 - 1;
+            tap_off = ((long)dh * p.W + dw) * p.C + c0;
+        } else {
+            const int tap = ks / cpt, c0 = (ks - tap * cpt) * BK;
+            tap_off = ((long)(tap >> 1) * 2 * p.W + (tap & 1)) * p.C + c0;
+        }
+#pragma unroll
+        for (int i = 0; i < A_INSTR; ++i) {
+            bool ok = a_ok[i];
+            if (AMODE == A_CONV3) {
+                const int h = (a_hw[i] >> 16) + dh, w = (a_hw[i] & 0xFFFF) + dw;
+                ok = ok && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
+            }
+            const bf16_t* src = ok ? p.A + a_off[i] + tap_off : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(abase + (wave + 4 * i) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < B_INSTR; ++i) {
+            const bf16_t* src = b_ok[i] ? p.B + b_off[i] + (long)ks * BK : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(abase + A_BYTES + (wave + 4 * i) * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BK;
+    stage(0, 0);
+    for (int ks = 0; ks < nk; ++ks) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (ks + 1 < nk) stage((ks + 1) & 1, ks + 1);
+        const unsigned char* abase = smem + (ks & 1) * STAGE;
+        const unsigned char* bbase = abase + A_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < BK / 32; ++kk) {
+            bf16x8 xa[FM], wb[FN];
+            const int chunk = kk * 4 + (lane >> 4);
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int row = wm * TM + i * 16 + (lane & 15);
+                xa[i] = *(const bf16x8*)(abase + row * ROWB + ((chunk ^ ((row >> SW) & (CH - 1))) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int row = wn * TN + j * 16 + (lane & 15);
+                wb[j] = *(const bf16x8*)(bbase + row * ROWB + ((chunk ^ ((row >> SW) & (CH - 1))) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue ----------------------------------------------------------------------
+    // acc[i][j][r]: pixel m = m0 + wm*TM + i*16 + (lane&15), column n = n0 + wn*TN + j*16 + (lane>>4)*4 + r
+    const bool want_stats = p.stat_sum != nullptr;
+    float ssum[FN][4], ssq[FN][4];
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ssum[j][r] = ssq[j][r] = 0.f;
+
+    float bv[FN][4];
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int n = n0 + wn * TN + j * 16 + (lane >> 4) * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[j][r] = 0.f;
+        if (p.bias && n < p.N) {
+            const float4 b4 = *(const float4*)(p.bias + (EPI == E_CONVT ? n % p.Co : n));
+            bv[j][0] = b4.x; bv[j][1] = b4.y; bv[j][2] = b4.z; bv[j][3] = b4.w;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int m = m0 + wm * TM + i * 16 + (lane & 15);
+        const bool mok = m < p.M;
+        long orow = 0;
+        if (EPI == E_CONVT) {
+            const int jj = m % p.W, t = m / p.W, ii = t % p.H, img = t / p.H;
+            orow = ((long)img * 2 * p.H + 2 * ii) * (2 * p.W) + 2 * jj;
+        }
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int n = n0 + wn * TN + j * 16 + (lane >> 4) * 4;
+            const bool ok = mok && n < p.N;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = acc[i][j][r] + bv[j][r];
+                if (EPI == E_TANH_BF16) v[r] = tanhf(v[r]);
+            }
+            if (want_stats && ok) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { ssum[j][r] += v[r]; ssq[j][r] += v[r] * v[r]; }
+            }
+            if (!ok) continue;
+            if (EPI == E_BF16 || EPI == E_TANH_BF16) {
+                *(uint2*)((bf16_t*)p.out + (long)m * p.ldo + n) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+            } else if (EPI == E_CONVT) {
+                const int tap = n / p.Co, co = n - tap * p.Co;
+                const long pix = orow + (long)(tap >> 1) * (2 * p.W) + (tap & 1);
+                *(uint2*)((bf16_t*)p.out + pix * p.Co + co) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+            } else if (EPI == E_F32_SPLIT) {
+                float* dst = n < p.split ? (float*)p.out + (long)m * p.split + n
+                                         : (float*)p.out2 + (long)m * p.split + (n - p.split);
+                *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                *(float4*)((float*)p.out + (long)m * p.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+
+    if (want_stats) {
+        __syncthreads();   // every wave is done reading the staging buffers
+        float* red = (float*)smem;   // [2][WAVES_M][BN]
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s = ssum[j][r], q = ssq[j][r];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    s += __shfl_xor(s, o, 64);
+                    q += __shfl_xor(q, o, 64);
+                }
+                if ((lane & 15) == 0) {
+                    const int c = wn * TN + j * 16 + (lane >> 4) * 4 + r;
+                    red[wm * BN + c] = s;
+                    red[(WAVES_M + wm) * BN + c] = q;
+                }
+            }
+        __syncthreads();
+        if (tid < BN && n0 + tid < p.N) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES_M; ++w) { s += red[w * BN + tid]; q += red[(WAVES_M + w) * BN + tid]; }
+            p.stat_sum[(long)blockIdx.x * p.N + n0 + tid] = s;
+            p.stat_sq[(long)blockIdx.x * p.N + n0 + tid] = q;
+        }
+    }
+}
+
+template <int BM, int BN, int BK, int WAVES_M, int AMODE, int EPI>
+static int launch_one(const GemmTN& p, hipStream_t s) {
+    dim3 grid((p.M + BM - 1) / BM, (p.N + BN - 1) / BN);
+    hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, BK, WAVES_M, AMODE, EPI>), grid, dim3(256), 0, s, p);
+    VAE_LAUNCH_CHECK("gemm_tn_kernel");
+    return 0;
+}
+
+template <int AMODE, int EPI>
+static int launch_bk64(const GemmTN& p, hipStream_t s) {
+    if (p.N <= 64) return launch_one<128, 64, 64, 4, AMODE, EPI>(p, s);
+    return launch_one<128, 128, 64, 2, AMODE, EPI>(p, s);
+}
+
+static int check_common(const GemmTN& p, int bk, const char* who) {
+    VAE_CHECK(p.A && p.B && p.out, "%s: null pointer", who);
+    VAE_CHECK(p.M > 0 && p.N > 0 && p.K > 0, "%s: empty problem M=%d N=%d K=%d", who, p.M, p.N, p.K);
+    VAE_CHECK(p.K % bk == 0, "%s: K=%d must be a multiple of %d", who, p.K, bk);
+    VAE_CHECK(p.N % 4 == 0, "%s: N=%d must be a multiple of 4", who, p.N);
+    VAE_CHECK((((uintptr_t)p.A | (uintptr_t)p.B | (uintptr_t)p.out | (uintptr_t)p.out2) & 15) == 0,
+              "%s: operands must be 16-byte aligned", who);
+    VAE_CHECK((p.stat_sum == nullptr) == (p.stat_sq == nullptr), "%s: stat_sum/stat_sq must both be set or both null", who);
+    return 0;
+}
+
+}  // namespace vae
+
+using namespace vae;
+
+extern "C" int vae_gemm_rows_per_block(void) { return 128; }
+
+extern "C" int vae_conv3x3_gemm(const void* x, const void* w_packed, const float* bias, void* y,
+                                float* stat_sum, float* stat_sq, int n_img, int H, int W, int Cin,
+                                int Cout, void* stream) {
+    GemmTN p = {};
+    p.A = (const bf16_t*)x; p.B = (const bf16_t*)w_packed; p.bias = bias; p.out = y;
+    p.stat_sum = stat_sum; p.stat_sq = stat_sq;
+    VAE_CHECK(n_img > 0 && H > 0 && W > 0 && (long)n_img * H * W < (1L << 31), "vae_conv3x3_gemm: bad geometry n=%d H=%d W=%d", n_img, H, W);
+    VAE_CHECK(H < 65536 && W < 65536, "vae_conv3x3_gemm: H, W must be < 65536");
+    VAE_CHECK(Cin % 64 == 0, "vae_conv3x3_gemm: Cin=%d must be a multiple of 64 (use the im2col path below that)", Cin);
+    p.M = n_img * H * W; p.N = Cout; p.K = 9 * Cin; p.H = H; p.W = W; p.C = Cin; p.ldo = Cout;
+    if (int e = check_common(p, 64, "vae_conv3x3_gemm")) return e;
+    return launch_bk64<A_CONV3, E_BF16>(p, (hipStream_t)stream);
+}
+
+extern "C" int vae_convt2x2_fwd_gemm(const void* x, const void* w_packed, const float* bias, void* y,
+                                     float* stat_sum, float* stat_sq, int n_img, int H, int W, int Cin,
+                                     int Cout, void* stream) {
+    GemmTN p = {};
+    p.A = (const bf16_t*)x; p.B = (const bf16_t*)w_packed; p.bias = bias; p.out = y;
+    p.stat_sum = stat_sum; p.stat_sq = stat_sq;
+    VAE_CHECK(n_img > 0 && H > 0 && W > 0 && (long)n_img * H * W * 4 < (1L << 31), "vae_convt2x2_fwd_gemm: bad geometry");
+    VAE_CHECK(Cin % 64 == 0 && Cout % 4 == 0, "vae_convt2x2_fwd_gemm: Cin=%d must be a multiple of 64, Cout=%d of 4", Cin, Cout);
+    p.M = n_img * H * W; p.N = 4 * Cout; p.K = Cin; p.lda = Cin; p.H = H; p.W = W; p.Co = Cout;
+    if (int e = check_common(p, 64, "vae_convt2x2_fwd_gemm")) return e;
+    return launch_bk64<A_PLAIN, E_CONVT>(p, (hipStream_t)stream);
+}
+
+extern "C" int vae_convt2x2_dgrad_gemm(const void* dy, const void* w_packed, void* dx, int n_img, int H,
+                                       int W, int Cin, int Cout, void* stream) {
+    GemmTN p = {};
+    p.A = (const bf16_t*)dy; p.B = (const bf16_t*)w_packed; p.out = dx;
+    VAE_CHECK(n_img > 0 && H > 0 && W > 0 && (long)n_img * H * W * 4 < (1L << 31), "vae_convt2x2_dgrad_gemm: bad geometry");
+    VAE_CHECK(Cout % 64 == 0, "vae_convt2x2_dgrad_gemm: Cout=%d must be a multiple of 64", Cout);
+    p.M = n_img * H * W; p.N = Cin; p.K = 4 * Cout; p.H = H; p.W = W; p.C = Cout; p.ldo = Cin;
+    if (int e = check_common(p, 64, "vae_convt2x2_dgrad_gemm")) return e;
+    return launch_bk64<A_CONVT_DGRAD, E_BF16>(p, (hipStream_t)stream);
+}
+
+extern "C" int vae_linear_gemm(const void* a, const void* w, const float* bias, void* out, void* out2,
+                               float* stat_sum, float* stat_sq, int M, int N, int K, int epilogue,
+                               void* stream) {
+    GemmTN p = {};
+    p.A = (const bf16_t*)a; p.B = (const bf16_t*)w; p.bias = bias; p.out = out; p.out2 = out2;
+    p.stat_sum = stat_sum; p.stat_sq = stat_sq;
+    p.M = M; p.N = N; p.K = K; p.lda = K; p.ldo = N;
+    hipStream_t s = (hipStream_t)stream;
+    if (K % 64 != 0) {
+        VAE_CHECK(epilogue == VAE_EPI_BF16, "vae_linear_gemm: K=%d not a multiple of 64 is only supported with the bf16 epilogue", K);
+        if (int e = check_common(p, 32, "vae_linear_gemm")) return e;
+        if (N <= 64) return launch_one<128, 64, 32, 4, A_PLAIN, E_BF16>(p, s);
+        return launch_one<128, 128, 32, 2, A_PLAIN, E_BF16>(p, s);
+    }
+    if (int e = check_common(p, 64, "vae_linear_gemm")) return e;
+    switch (epilogue) {
+        case VAE_EPI_BF16: return launch_bk64<A_PLAIN, E_BF16>(p, s);
+        case VAE_EPI_TANH_BF16: return launch_bk64<A_PLAIN, E_TANH_BF16>(p, s);
+        case VAE_EPI_F32: return launch_bk64<A_PLAIN, E_F32>(p, s);
+        case VAE_EPI_F32_SPLIT:
+            VAE_CHECK(out2 && N % 2 == 0 && (N / 2) % 4 == 0, "vae_linear_gemm: split epilogue needs out2 and N/2 a multiple of 4");
+            p.split = N / 2;
+            return launch_bk64<A_PLAIN, E_F32_SPLIT>(p, s);
+        default:
+            VAE_CHECK(false, "vae_linear_gemm: unknown epilogue %d", epilogue);
+    }
+    return 0;
+}

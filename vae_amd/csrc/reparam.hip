@@ -1,0 +1,218 @@
+// Reparameterisation sample fused with the KL term, forward and backward, plus the raw
+// Philox stream kernels used by the RNG parity tests.
+//
+//   z   = mu + exp(0.5*logvar) * eps            eps ~ N(0,1) from Philox4x32-10 (or injected)
+//   KL  = -0.5 * sum(1 + logvar - mu^2 - exp(logvar))
+//   dmu = dz + dmu_ext + kl_scale * mu
+//   dlv = dz * eps * 0.5 * exp(0.5*logvar) + dlv_ext + kl_scale * 0.5 * (exp(logvar) - 1)
+//
+// HBM-bound; forward moves 12 algorithmic bytes per latent element (mu, logvar in, z out),
+// eps is regenerated from the counter in the backward instead of being stored.
+#include "common.h"
+#include "../../include/vae_hip.h"
+
+namespace vae {
+
+__device__ __forceinline__ PhiloxKey make_key(unsigned long long seed, unsigned step,
+                                              unsigned stream, unsigned rank) {
+    PhiloxKey k;
+    k.seed_lo = (uint32_t)seed;
+    k.seed_hi = (uint32_t)(seed >> 32);
+    k.step = step;
+    k.stream = stream;
+    k.rank = rank;
+    return k;
+}
+
+__global__ __launch_bounds__(256) void reparam_kl_fwd_kernel(
+    const float* __restrict__ mu, const float* __restrict__ logvar, const float* __restrict__ eps_in,
+    float* __restrict__ z_f32, bf16_t* __restrict__ z_bf16, float* __restrict__ eps_out,
+    float* __restrict__ kl_partial, long n, unsigned long long seed, unsigned step, unsigned rank) {
+    __shared__ float red[8];
+    const PhiloxKey key = make_key(seed, step, VAE_STREAM_EPS, rank);
+    const long nblk = (n + 3) >> 2;
+    float acc = 0.f;
+    for (long b = (long)blockIdx.x * blockDim.x + threadIdx.x; b < nblk;
+         b += (long)gridDim.x * blockDim.x) {
+        const long i0 = b << 2;
+        float m[4], lv[4], e[4], z[4];
+        const bool full = i0 + 4 <= n;
+        if (full) {
+            const float4 m4 = *(const float4*)(mu + i0);
+            const float4 l4 = *(const float4*)(logvar + i0);
+            m[0] = m4.x; m[1] = m4.y; m[2] = m4.z; m[3] = m4.w;
+            lv[0] = l4.x; lv[1] = l4.y; lv[2] = l4.z; lv[3] = l4.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                m[j] = i0 + j < n ? mu[i0 + j] : 0.f;
+                lv[j] = i0 + j < n ? logvar[i0 + j] : 0.f;
+            }
+        }
+        if (eps_in) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) e[j] = i0 + j < n ? eps_in[i0 + j] : 0.f;
+        } else {
+            philox_normal4(key, (uint32_t)b, e);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float sd = expf(0.5f * lv[j]);
+            z[j] = m[j] + sd * e[j];
+            if (i0 + j < n) acc += 1.f + lv[j] - m[j] * m[j] - expf(lv[j]);
+        }
+        if (full) {
+            if (z_f32) *(float4*)(z_f32 + i0) = make_float4(z[0], z[1], z[2], z[3]);
+            if (z_bf16) *(uint2*)(z_bf16 + i0) = make_uint2(pack2bf(z[0], z[1]), pack2bf(z[2], z[3]));
+            if (eps_out) *(float4*)(eps_out + i0) = make_float4(e[0], e[1], e[2], e[3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (i0 + j < n) {
+                    if (z_f32) z_f32[i0 + j] = z[j];
+                    if (z_bf16) z_bf16[i0 + j] = f2bf(z[j]);
+                    if (eps_out) eps_out[i0 + j] = e[j];
+                }
+        }
+    }
+    const float s = block_sum(acc, red);
+    if (threadIdx.x == 0) kl_partial[blockIdx.x] = -0.5f * s;
+}
+
+// dcat (bf16, optional) holds [row][0:L] = dmu, [row][L:2L] = dlogvar, the operand layout of
+// the fused mu|logvar head's dgrad / wgrad GEMMs.
+__global__ __launch_bounds__(256) void reparam_kl_bwd_kernel(
+    const float* __restrict__ dz, const float* __restrict__ mu, const float* __restrict__ logvar,
+    const float* __restrict__ eps_in, const float* __restrict__ dmu_ext,
+    const float* __restrict__ dlv_ext, float kl_scale, float* __restrict__ dmu,
+    float* __restrict__ dlv, bf16_t* __restrict__ dcat, long n, int L, unsigned long long seed,
+    unsigned step, unsigned rank) {
+    const PhiloxKey key = make_key(seed, step, VAE_STREAM_EPS, rank);
+    const long nblk = (n + 3) >> 2;
+    for (long b = (long)blockIdx.x * blockDim.x + threadIdx.x; b < nblk;
+         b += (long)gridDim.x * blockDim.x) {
+        const long i0 = b << 2;
+        float e[4];
+        if (eps_in) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) e[j] = i0 + j < n ? eps_in[i0 + j] : 0.f;
+        } else {
+            philox_normal4(key, (uint32_t)b, e);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long i = i0 + j;
+            if (i >= n) break;
+            const float g = dz ? dz[i] : 0.f;
+            const float lv = logvar[i];
+            const float sd = expf(0.5f * lv);
+            float gm = g + kl_scale * mu[i];
+            float gl = g * e[j] * 0.5f * sd + kl_scale * 0.5f * (expf(lv) - 1.f);
+            if (dmu_ext) gm += dmu_ext[i];
+            if (dlv_ext) gl += dlv_ext[i];
+            if (dmu) dmu[i] = gm;
+            if (dlv) dlv[i] = gl;
+            if (dcat) {
+                const long row = i / L;
+                const int col = (int)(i - row * L);
+                dcat[row * 2 * L + col] = f2bf(gm);
+                dcat[row * 2 * L + L + col] = f2bf(gl);
+            }
+        }
+    }
+}
+
+// MODE 0: raw uint32 words, 1: normals (fp32), 2: keep-mask bytes ((word >> 8) >= thr)
+template <int MODE>
+__global__ __launch_bounds__(256) void philox_fill_kernel(void* __restrict__ out, long n,
+                                                          PhiloxKey key, uint32_t thr) {
+    const long nblk = (n + 3) >> 2;
+    for (long b = (long)blockIdx.x * blockDim.x + threadIdx.x; b < nblk;
+         b += (long)gridDim.x * blockDim.x) {
+        const long i0 = b << 2;
+        if (MODE == 1) {
+            float z[4];
+            philox_normal4(key, (uint32_t)b, z);
+            for (int j = 0; j < 4 && i0 + j < n; ++j) ((float*)out)[i0 + j] = z[j];
+        } else {
+            uint32_t w[4];
+            philox_block(key, (uint32_t)b, w);
+            for (int j = 0; j < 4 && i0 + j < n; ++j) {
+                if (MODE == 0) ((uint32_t*)out)[i0 + j] = w[j];
+                else ((uint8_t*)out)[i0 + j] = (w[j] >> 8) >= thr ? 1 : 0;
+            }
+        }
+    }
+}
+
+}  // namespace vae
+
+using namespace vae;
+
+extern "C" int vae_reparam_grid(long n_elems) {
+    long blocks = ((n_elems + 3) / 4 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    return (int)blocks;
+}
+
+extern "C" int vae_reparam_kl_fwd(const float* mu, const float* logvar, const float* eps_in,
+                                  float* z_f32, void* z_bf16, float* eps_out, float* kl_partial,
+                                  long n_elems, unsigned long long seed, unsigned step,
+                                  unsigned rank, void* stream) {
+    VAE_CHECK(mu && logvar && kl_partial, "vae_reparam_kl_fwd: null pointer");
+    VAE_CHECK(n_elems > 0, "vae_reparam_kl_fwd: n_elems must be > 0 (got %ld)", n_elems);
+    VAE_CHECK((((uintptr_t)mu | (uintptr_t)logvar | (uintptr_t)z_f32 | (uintptr_t)eps_out) & 15) == 0 &&
+                  ((uintptr_t)z_bf16 & 7) == 0,
+              "vae_reparam_kl_fwd: pointers must be 16-byte aligned");
+    VAE_CHECK(n_elems < (1L << 34), "vae_reparam_kl_fwd: n_elems too large for a 32-bit block counter");
+    const int grid = vae_reparam_grid(n_elems);
+    hipLaunchKernelGGL(reparam_kl_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, mu,
+                       logvar, eps_in, z_f32, (bf16_t*)z_bf16, eps_out, kl_partial, n_elems, seed,
+                       step, rank);
+    VAE_LAUNCH_CHECK("reparam_kl_fwd_kernel");
+    return 0;
+}
+
+extern "C" int vae_reparam_kl_bwd(const float* dz, const float* mu, const float* logvar,
+                                  const float* eps_in, const float* dmu_ext, const float* dlv_ext,
+                                  float kl_scale, float* dmu, float* dlv, void* dcat_bf16,
+                                  long n_elems, int latent, unsigned long long seed, unsigned step,
+                                  unsigned rank, void* stream) {
+    VAE_CHECK(mu && logvar, "vae_reparam_kl_bwd: null pointer");
+    VAE_CHECK(n_elems > 0 && latent > 0 && n_elems % latent == 0,
+              "vae_reparam_kl_bwd: n_elems (%ld) must be a positive multiple of latent (%d)",
+              n_elems, latent);
+    const int grid = vae_reparam_grid(n_elems);
+    hipLaunchKernelGGL(reparam_kl_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dz, mu,
+                       logvar, eps_in, dmu_ext, dlv_ext, kl_scale, dmu, dlv, (bf16_t*)dcat_bf16,
+                       n_elems, latent, seed, step, rank);
+    VAE_LAUNCH_CHECK("reparam_kl_bwd_kernel");
+    return 0;
+}
+
+extern "C" int vae_philox_fill(void* out, long n, int mode, double p_drop, unsigned long long seed,
+                               unsigned step, unsigned stream_id, unsigned rank, void* stream) {
+    VAE_CHECK(out && n > 0, "vae_philox_fill: bad arguments");
+    VAE_CHECK(mode >= 0 && mode <= 2, "vae_philox_fill: unknown mode %d", mode);
+    PhiloxKey key;
+    key.seed_lo = (uint32_t)seed; key.seed_hi = (uint32_t)(seed >> 32);
+    key.step = step; key.stream = stream_id; key.rank = rank;
+    const uint32_t thr = vae_dropout_threshold(p_drop);
+    const int grid = vae_reparam_grid(n);
+    hipStream_t s = (hipStream_t)stream;
+    if (mode == 0) hipLaunchKernelGGL(philox_fill_kernel<0>, dim3(grid), dim3(256), 0, s, out, n, key, thr);
+    else if (mode == 1) hipLaunchKernelGGL(philox_fill_kernel<1>, dim3(grid), dim3(256), 0, s, out, n, key, thr);
+    else hipLaunchKernelGGL(philox_fill_kernel<2>, dim3(grid), dim3(256), 0, s, out, n, key, thr);
+    VAE_LAUNCH_CHECK("philox_fill_kernel");
+    return 0;
+}
+
+extern "C" unsigned vae_dropout_threshold(double p_drop) {
+    double t = p_drop * 16777216.0;
+    double c = (double)(unsigned long long)t;
+    if (c < t) c += 1.0;
+    if (c > 16777216.0) c = 16777216.0;
+    if (c < 0) c = 0;
+    return (unsigned)c;
+}
