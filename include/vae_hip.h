@@ -84,6 +84,12 @@ int vae_gemm_rows_per_block(void);
 int vae_conv3x3_gemm(const void* x, const void* w_packed, const float* bias, void* y,
                      float* stat_sum, float* stat_sq, int n_img, int H, int W, int Cin, int Cout,
                      void* stream);
+/* The first conv, nn.Conv2d(in_channels<=8, 64, 3, padding=1), vae/models/vae.py:34,129:
+ * x8 is the network input as NHWC bf16 padded to 8 channels, w_packed [Cout][16 taps][8]
+ * (taps 9..15 and channels >= in_channels are zero). */
+int vae_conv3x3_c8_gemm(const void* x8, const void* w_packed, const float* bias, void* y,
+                        float* stat_sum, float* stat_sq, int n_img, int H, int W, int Cout,
+                        void* stream);
 /* nn.ConvTranspose2d(Cin, Cout, 2, stride=2) forward, vae/models/vae.py:64,67,70.
  * x [n,H,W,Cin], w_packed [(kh,kw,co)][Cin], y [n,2H,2W,Cout]; stats are per GEMM column
  * (tap*Cout + co), 4*Cout of them. */
@@ -98,6 +104,74 @@ int vae_convt2x2_dgrad_gemm(const void* dy, const void* w_packed, void* dx, int 
 int vae_linear_gemm(const void* a, const void* w, const float* bias, void* out, void* out2,
                     float* stat_sum, float* stat_sq, int M, int N, int K, int epilogue,
                     void* stream);
+
+/* ---- weight gradients (what autograd computes for the layers above in loss.backward(),
+ *      vae/training/train.py:332) ------------------------------------------------------------ */
+#define VAE_WGRAD_PLAIN 0     /* dW[m][n]      = sum_k P[k][m] Q[k][n]                 (nn.Linear)          */
+#define VAE_WGRAD_CONV3 1     /* dW[m][tap][n] = sum_pix dY[pix][m] X[pix+tap][n]      (Conv2d 3x3 p1)      */
+#define VAE_WGRAD_CONVT 2     /* dW[m][tap][n] = sum_pix dY[2i+kh,2j+kw][m] X[pix][n]  (ConvTranspose k2s2) */
+#define VAE_WGRAD_CONV3_C8 3  /* first conv: Q = 8-channel input, dW[m][16 taps][8]                          */
+/* suggested K split for a problem (keeps the chip full) */
+int vae_wgrad_ksplit(int M, int N, int taps, long Ktot);
+/* P [K rows][ldp] (M channels used), Q [K rows][ldq] (N channels used), both bf16.
+ * slab: nsplit x taps x M x N floats, written as [split][m][tap][n].  H, W: pixel grid of K
+ * (ignored for PLAIN). */
+int vae_wgrad_gemm(const void* P, const void* Q, float* slab, int M, int N, long Ktot, int ldp,
+                   int ldq, int mode, int H, int W, int nsplit, void* stream);
+/* out[e] (+)= sum_s slab[s*slab_stride + base + i0*s0+i1*s1+i2*s2+i3*s3] where e is the row-major
+ * index over dims4 = (D0,D1,D2,D3): folds the K splits and converts the kernels' packed
+ * layout to the parameter's own layout (e.g. Conv2d [Cout][Cin][3][3]). */
+int vae_reduce_slabs(const float* slab, int nsplit, long slab_stride, float* out, const long* dims4,
+                     const long* strides4, long base, int accumulate, void* stream);
+/* dst_bf16[base + i0*s0+i1*s1+i2*s2+i3*s3] = bf16(src[e]): fp32 parameter -> packed bf16 operand */
+int vae_pack_bf16(const float* src, void* dst_bf16, const long* dims4, const long* strides4,
+                  long base, void* stream);
+
+/* ---- BatchNorm2d + ReLU + Dropout + MaxPool2d(2): the tail of DoubleConv and the pools,
+ *      vae/models/vae.py:130-137,35,38,41, and bn3/bn2/bn1 + relu, vae.py:119-121 ------------- */
+/* Folds the GEMM epilogue's per-workgroup sums (rows x fold*C) into scale = gamma*rstd,
+ * shift = beta - mean*scale, mean, rstd, and moves running_mean / running_var (momentum 0.1,
+ * unbiased variance) when they are given.  use_running = 1: eval mode, stats are not read. */
+int vae_bn_finalize(const float* stat_sum, const float* stat_sq, int rows, int C, int fold,
+                    double count, const float* gamma, const float* beta, float* running_mean,
+                    float* running_var, float momentum, float eps, int use_running, float* scale,
+                    float* shift, float* mean, float* rstd, void* stream);
+/* out[j] = mul * sum_r partial[r][j] */
+int vae_sum_partials(const float* partial, int rows, int ncols, float* out, float mul, void* stream);
+/* y [n,H,W,C] -> out [n,H,W,C] or, with pool, [n,H/2,W/2,C].  Dropout keep flags come from
+ * keep_mask (uint8, y's layout) when given, else from Philox(seed, step, stream_id, rank) at the
+ * element's NHWC linear index. */
+int vae_bn_act_fwd(const void* y, const float* scale, const float* shift, void* out, int n_img,
+                   int H, int W, int C, int pool, double p_drop, const void* keep_mask,
+                   unsigned long long seed, unsigned step, unsigned stream_id, unsigned rank,
+                   void* stream);
+/* rows of the `partial` workspace (x 2*C floats) used by vae_bn_act_bwd */
+int vae_bn_act_bwd_blocks(int n_img, int H, int W, int C, int pool);
+/* backward of the above down to the conv output: gin = grad of the (pooled) block output,
+ * dy = grad of the pre-norm tensor y; sums = [d gamma (C) | d beta (C)]. */
+int vae_bn_act_bwd(const void* gin, const void* y, const float* scale, const float* shift,
+                   const float* mean, const float* rstd, float* partial, float* sums, void* dy,
+                   int n_img, int H, int W, int C, int pool, double p_drop, const void* keep_mask,
+                   unsigned long long seed, unsigned step, unsigned stream_id, unsigned rank,
+                   void* stream);
+/* relu(bn1(.)) -> nn.Conv2d(64, Cout, 1) -> sigmoid, vae/models/vae.py:74,121-122.
+ * y [n,H,W,64] bf16, w [Cout][64] f32, recon [n,Cout,H,W] f32 (NCHW, the module output). */
+int vae_head_fwd(const void* y, const float* scale, const float* shift, const float* w,
+                 const float* b, float* recon, int n_img, int H, int W, int Cout, void* stream);
+int vae_head_bwd_blocks(int n_img, int H, int W);
+/* its backward: partial is blocks x (3+Cout)*64 floats; sums = [d gamma1(64) | d beta1(64) |
+ * dW[Cout][64] | db (Cout, padded to 64)]; dy [n,H,W,64] bf16 = grad of up1's output. */
+int vae_head_bwd(const float* drecon, const float* recon, const void* y, const float* scale,
+                 const float* shift, const float* mean, const float* rstd, const float* w,
+                 float* partial, float* sums, void* dy, int n_img, int H, int W, int Cout,
+                 void* stream);
+/* torch.tanh backward (vae.py:116): dpre = dx*(1-h^2), colpartial [vae_tanh_bwd_rows(rows)][cols]
+ * = per-row-group column sums of dpre (fc_up bias gradient). */
+int vae_tanh_bwd_rows(int rows);
+int vae_tanh_bwd(const void* dx, const void* h, void* dpre, float* colpartial, int rows, int cols,
+                 void* stream);
+/* inputs.to(device) (train.py:325): NCHW f32 image batch -> NHWC bf16 padded to 8 channels */
+int vae_nchw_to_nhwc8(const float* x, void* out, int n_img, int C, int H, int W, void* stream);
 
 #ifdef __cplusplus
 }

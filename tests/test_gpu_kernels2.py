@@ -1,0 +1,284 @@
+"""Parity of the weight-gradient GEMM, the first-conv path, BatchNorm/ReLU/Dropout/MaxPool,
+the 1x1 head and the small helpers against the CPU oracle (through the C ABI).
+
+bf16 kernels are checked against the oracle evaluated on the same bf16-rounded operands
+(see test_gpu_kernels.py for the tolerance rationale); fp32 outputs (statistics, parameter
+gradients, recon) to 1e-4 .. 1e-5 relative per tensor."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import vae_oracle as O
+from golden_util import rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def L():
+    from vae_amd import _lib
+    _lib.load()
+    return _lib
+
+
+def bf(t):
+    return t.to(torch.bfloat16).float()
+
+
+def nhwc(t, dtype=torch.bfloat16):
+    return t.permute(0, 2, 3, 1).contiguous().to(dtype).to(DEV)
+
+
+def from_nhwc(t):
+    return t.float().cpu().permute(0, 3, 1, 2)
+
+
+def check_bf16(got, ref, what, rtol=3e-3):
+    err = (got - ref).abs()
+    tol = ref.abs() * 2.0 ** -8 + 1e-3 * ref.abs().max()
+    assert (err <= tol).all(), f"{what}: max err {err.max().item()} (ref max {ref.abs().max().item()})"
+    assert rel_l2(got, ref) <= rtol, what
+
+
+def wgrad(L, P, Q, M, N, K, ldp, ldq, mode, H, W, taps, nsplit=None):
+    s = nsplit or L.call("vae_wgrad_ksplit", M, N, taps, K)
+    slab = torch.full((s, M, taps, N), float("nan"), device=DEV)
+    L.call("vae_wgrad_gemm", L.ptr(P), L.ptr(Q), L.ptr(slab), M, N, K, ldp, ldq, mode, H, W, s, L.current_stream())
+    return slab, s
+
+
+# ------------------------------------------------------------------ first conv (8-channel input)
+@pytest.mark.parametrize("n,H,W,Ci", [(2, 8, 8, 3), (3, 32, 32, 3), (1, 6, 10, 1)])
+def test_conv_c8_fwd_and_wgrad(L, n, H, W, Ci):
+    g = torch.Generator().manual_seed(n + H)
+    Co = 64
+    x = bf(torch.rand(n, Ci, H, W, generator=g))
+    w = bf(torch.randn(Co, Ci, 3, 3, generator=g) / 5)
+    b = torch.randn(Co, generator=g)
+    ref = F.conv2d(x, w, b, padding=1)
+    xd = x.to(DEV)
+    x8 = torch.full((n, H, W, 8), float("nan"), device=DEV, dtype=torch.bfloat16)
+    L.call("vae_nchw_to_nhwc8", L.ptr(xd), L.ptr(x8), n, Ci, H, W, L.current_stream())
+    exp8 = torch.zeros(n, H, W, 8)
+    exp8[..., :Ci] = x.permute(0, 2, 3, 1)
+    assert torch.equal(x8.float().cpu(), exp8)
+    # pack [Co][16 taps][8] with the pack kernel: ref index (co, ci, tap) -> co*128 + tap*8 + ci
+    wp = torch.zeros(Co, 16, 8, device=DEV, dtype=torch.bfloat16)
+    wd = w.to(DEV)
+    L.call("vae_pack_bf16", L.ptr(wd), L.ptr(wp), L.long4(Co, Ci, 9, 1), L.long4(128, 1, 8, 0), 0, L.current_stream())
+    exp = torch.zeros(Co, 16, 8)
+    exp[:, :9, :Ci] = w.permute(0, 2, 3, 1).reshape(Co, 9, Ci)
+    assert torch.equal(wp.float().cpu(), exp)
+    bd = b.to(DEV)
+    y = torch.full((n, H, W, Co), float("nan"), device=DEV, dtype=torch.bfloat16)
+    L.call("vae_conv3x3_c8_gemm", L.ptr(x8), L.ptr(wp), L.ptr(bd), L.ptr(y), None, None, n, H, W, Co, L.current_stream())
+    check_bf16(from_nhwc(y), ref, "conv c8 fwd")
+    # weight gradient
+    dy = bf(torch.randn(n, Co, H, W, generator=g))
+    wr = w.clone().requires_grad_(True)
+    F.conv2d(x, wr, None, padding=1).backward(dy)
+    dyd = nhwc(dy)
+    slab, s = wgrad(L, dyd, x8, Co, 64, n * H * W, Co, 8, 3, H, W, 2)
+    dw = torch.full((Co, Ci, 3, 3), float("nan"), device=DEV)
+    L.call("vae_reduce_slabs", L.ptr(slab), s, Co * 128, L.ptr(dw), L.long4(Co, Ci, 9, 1), L.long4(128, 1, 8, 0), 0, 0,
+           L.current_stream())
+    assert rel_l2(dw.cpu(), wr.grad) <= 1e-4
+
+
+# ------------------------------------------------------------------ weight gradients
+@pytest.mark.parametrize("n,H,W,Ci,Co", [(2, 4, 4, 64, 64), (3, 8, 8, 64, 128), (2, 16, 16, 128, 128),
+                                         (5, 4, 4, 256, 256), (2, 32, 32, 64, 64), (1, 6, 10, 128, 64)])
+def test_conv3x3_wgrad(L, n, H, W, Ci, Co):
+    g = torch.Generator().manual_seed(n + H + Ci)
+    x = bf(torch.randn(n, Ci, H, W, generator=g))
+    dy = bf(torch.randn(n, Co, H, W, generator=g))
+    w = torch.zeros(Co, Ci, 3, 3, requires_grad=True)
+    F.conv2d(x, w, None, padding=1).backward(dy)
+    xd, dyd = nhwc(x), nhwc(dy)
+    slab, s = wgrad(L, dyd, xd, Co, Ci, n * H * W, Co, Ci, 1, H, W, 9)
+    dw = torch.full((Co, Ci, 3, 3), float("nan"), device=DEV)
+    # ref index (co, ci, tap) -> packed co*(9*Ci) + tap*Ci + ci
+    L.call("vae_reduce_slabs", L.ptr(slab), s, 9 * Co * Ci, L.ptr(dw), L.long4(Co, Ci, 9, 1), L.long4(9 * Ci, 1, Ci, 0),
+           0, 0, L.current_stream())
+    assert rel_l2(dw.cpu(), w.grad) <= 1e-4
+    # accumulate flag adds on top
+    L.call("vae_reduce_slabs", L.ptr(slab), s, 9 * Co * Ci, L.ptr(dw), L.long4(Co, Ci, 9, 1), L.long4(9 * Ci, 1, Ci, 0),
+           0, 1, L.current_stream())
+    assert rel_l2(dw.cpu(), 2 * w.grad) <= 1e-4
+
+
+@pytest.mark.parametrize("n,H,W,Ci,Co", [(2, 4, 4, 256, 128), (3, 8, 8, 128, 64), (2, 16, 16, 64, 64), (1, 3, 5, 64, 64)])
+def test_convt_wgrad(L, n, H, W, Ci, Co):
+    g = torch.Generator().manual_seed(n + H + Ci)
+    x = bf(torch.randn(n, Ci, H, W, generator=g))
+    dy = bf(torch.randn(n, Co, 2 * H, 2 * W, generator=g))
+    w = torch.zeros(Ci, Co, 2, 2, requires_grad=True)
+    F.conv_transpose2d(x, w, None, stride=2).backward(dy)
+    xd, dyd = nhwc(x), nhwc(dy)
+    slab, s = wgrad(L, dyd, xd, Co, Ci, n * H * W, Co, Ci, 2, H, W, 4)
+    dw = torch.full((Ci, Co, 2, 2), float("nan"), device=DEV)
+    # ref index (ci, co, tap) -> packed co*(4*Ci) + tap*Ci + ci
+    L.call("vae_reduce_slabs", L.ptr(slab), s, 4 * Co * Ci, L.ptr(dw), L.long4(Ci, Co, 4, 1), L.long4(1, 4 * Ci, Ci, 0),
+           0, 0, L.current_stream())
+    assert rel_l2(dw.cpu(), w.grad) <= 1e-4
+
+
+@pytest.mark.parametrize("rows,M,N", [(4, 256, 4096), (512, 256, 1024), (130, 4096, 128), (7, 64, 64)])
+def test_linear_wgrad(L, rows, M, N):
+    g = torch.Generator().manual_seed(rows + M)
+    dout = bf(torch.randn(rows, M, generator=g))
+    x = bf(torch.randn(rows, N, generator=g))
+    ref = dout.t() @ x
+    dd, xd = dout.to(torch.bfloat16).to(DEV), x.to(torch.bfloat16).to(DEV)
+    slab, s = wgrad(L, dd, xd, M, N, rows, M, N, 0, 1, 1, 1)
+    dw = torch.full((M, N), float("nan"), device=DEV)
+    L.call("vae_reduce_slabs", L.ptr(slab), s, M * N, L.ptr(dw), L.long4(M, N, 1, 1), L.long4(N, 1, 0, 0), 0, 0,
+           L.current_stream())
+    assert rel_l2(dw.cpu(), ref) <= 1e-4
+
+
+# ------------------------------------------------------------------ BatchNorm / ReLU / Dropout / MaxPool
+def stats_inputs(y_nchw):
+    yn = y_nchw.permute(0, 2, 3, 1).reshape(-1, y_nchw.shape[1])
+    return yn.sum(0, keepdim=True).contiguous().to(DEV), (yn ** 2).sum(0, keepdim=True).contiguous().to(DEV)
+
+
+@pytest.mark.parametrize("n,H,W,C,pool,p", [(4, 8, 8, 64, 0, 0.0), (3, 8, 8, 128, 1, 0.0), (2, 16, 16, 64, 1, 0.1),
+                                            (5, 4, 4, 256, 0, 0.1), (2, 6, 10, 128, 1, 0.3)])
+@pytest.mark.parametrize("inject", [False, True])
+def test_bn_act_fwd_bwd(L, n, H, W, C, pool, p, inject):
+    g = torch.Generator().manual_seed(n + H + C + pool)
+    y = bf(torch.randn(n, C, H, W, generator=g) * 1.5 + 0.3)
+    gamma = 0.5 + torch.rand(C, generator=g)
+    beta = 0.4 * torch.rand(C, generator=g) - 0.2
+    rm, rv = torch.randn(C, generator=g) * 0.1, 0.5 + torch.rand(C, generator=g)
+    seed, step, stream_id, rank = 99, 3, 2, 1
+    M = n * H * W
+    if p > 0:
+        if inject:
+            mask_nhwc = (torch.rand(n, H, W, C, generator=g) >= p).to(torch.uint8)
+        else:
+            mask_nhwc = torch.from_numpy(O.philox_keep_mask(M * C, p, seed, stream_id, step, rank)).view(n, H, W, C)
+        mask = mask_nhwc.permute(0, 3, 1, 2)
+    else:
+        mask_nhwc = mask = None
+    # ---- oracle
+    yr, gr, br = y.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    stats = {}
+    a = O.dropout(torch.relu(O.batch_norm(yr, gr, br, rm, rv, True, stats, "bn")), p, True, mask)
+    out_ref = F.max_pool2d(a, 2) if pool else a
+    gin = bf(torch.randn(out_ref.shape, generator=g))
+    (out_ref * gin).sum().backward()
+    # ---- HIP
+    ssum, ssq = stats_inputs(y)
+    gd, bd, rmd, rvd = gamma.to(DEV), beta.to(DEV), rm.to(DEV), rv.to(DEV)
+    sc, sh, mean, rstd = (torch.empty(C, device=DEV) for _ in range(4))
+    L.call("vae_bn_finalize", L.ptr(ssum), L.ptr(ssq), 1, C, 1, float(M), L.ptr(gd), L.ptr(bd), L.ptr(rmd), L.ptr(rvd),
+           0.1, 1e-5, 0, L.ptr(sc), L.ptr(sh), L.ptr(mean), L.ptr(rstd), L.current_stream())
+    assert rel_l2(rmd.cpu(), stats["bn.running_mean"]) <= 1e-5
+    assert rel_l2(rvd.cpu(), stats["bn.running_var"]) <= 1e-5
+    yd = nhwc(y)
+    md = mask_nhwc.contiguous().to(DEV) if (inject and p > 0) else None
+    out = torch.full(tuple(nhwc(out_ref).shape), float("nan"), device=DEV, dtype=torch.bfloat16)
+    L.call("vae_bn_act_fwd", L.ptr(yd), L.ptr(sc), L.ptr(sh), L.ptr(out), n, H, W, C, pool, p, L.ptr(md), seed, step,
+           stream_id, rank, L.current_stream())
+    check_bf16(from_nhwc(out), out_ref.detach(), "bn_act fwd")
+    gind = nhwc(gin)
+    nb = L.call("vae_bn_act_bwd_blocks", n, H, W, C, pool)
+    partial = torch.full((nb, 2 * C), float("nan"), device=DEV)
+    sums = torch.full((2 * C,), float("nan"), device=DEV)
+    dy = torch.full((n, H, W, C), float("nan"), device=DEV, dtype=torch.bfloat16)
+    L.call("vae_bn_act_bwd", L.ptr(gind), L.ptr(yd), L.ptr(sc), L.ptr(sh), L.ptr(mean), L.ptr(rstd), L.ptr(partial),
+           L.ptr(sums), L.ptr(dy), n, H, W, C, pool, p, L.ptr(md), seed, step, stream_id, rank, L.current_stream())
+    assert rel_l2(sums[:C].cpu(), gr.grad) <= 2e-5
+    assert rel_l2(sums[C:].cpu(), br.grad) <= 2e-5
+    check_bf16(from_nhwc(dy), yr.grad, "bn_act bwd", rtol=4e-3)
+
+
+def test_bn_finalize_eval_and_fold(L):
+    C = 64
+    g = torch.Generator().manual_seed(5)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.rand(C, generator=g)
+    rm, rv = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+    gd, bd, rmd, rvd = gamma.to(DEV), beta.to(DEV), rm.to(DEV), rv.to(DEV)
+    sc, sh, mean, rstd = (torch.empty(C, device=DEV) for _ in range(4))
+    L.call("vae_bn_finalize", None, None, 0, C, 1, 0.0, L.ptr(gd), L.ptr(bd), L.ptr(rmd), L.ptr(rvd), 0.1, 1e-5, 1,
+           L.ptr(sc), L.ptr(sh), L.ptr(mean), L.ptr(rstd), L.current_stream())
+    s_ref = gamma / torch.sqrt(rv + 1e-5)
+    assert rel_l2(sc.cpu(), s_ref) <= 1e-6 and rel_l2(sh.cpu(), beta - rm * s_ref) <= 1e-6
+    assert torch.equal(rmd.cpu(), rm) and torch.equal(rvd.cpu(), rv)      # eval leaves running stats alone
+    # fold = 4 (ConvTranspose columns tap*C + c), 37 partial rows
+    rows = 37
+    ps = torch.randn(rows, 4 * C, generator=g)
+    pq = torch.rand(rows, 4 * C, generator=g) * 30 + 40
+    psd, pqd = ps.to(DEV), pq.to(DEV)
+    count = 5000.0
+    L.call("vae_bn_finalize", L.ptr(psd), L.ptr(pqd), rows, C, 4, count, L.ptr(gd), L.ptr(bd), None, None, 0.1, 1e-5, 0,
+           L.ptr(sc), L.ptr(sh), L.ptr(mean), L.ptr(rstd), L.current_stream())
+    m_ref = ps.double().sum(0).view(4, C).sum(0) / count
+    v_ref = pq.double().sum(0).view(4, C).sum(0) / count - m_ref ** 2
+    assert rel_l2(mean.cpu(), m_ref) <= 1e-6
+    assert rel_l2(rstd.cpu(), 1 / torch.sqrt(v_ref + 1e-5)) <= 1e-6
+
+
+# ------------------------------------------------------------------ head
+@pytest.mark.parametrize("n,H,W,Co", [(2, 8, 8, 3), (3, 32, 32, 3), (1, 5, 7, 1), (2, 4, 4, 4)])
+def test_head_fwd_bwd(L, n, H, W, Co):
+    g = torch.Generator().manual_seed(n + H + Co)
+    C = 64
+    y = bf(torch.randn(n, C, H, W, generator=g))
+    gamma, beta = 0.5 + torch.rand(C, generator=g), 0.4 * torch.rand(C, generator=g) - 0.2
+    w = torch.randn(Co, C, 1, 1, generator=g) * 0.2
+    b = torch.randn(Co, generator=g) * 0.1
+    rm, rv = torch.zeros(C), torch.ones(C)
+    yr = y.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    wr, bbr = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    a = torch.relu(O.batch_norm(yr, gr, br, rm, rv, True))
+    recon_ref = torch.sigmoid(F.conv2d(a, wr, bbr))
+    dr = torch.randn(recon_ref.shape, generator=g)
+    (recon_ref * dr).sum().backward()
+    M = n * H * W
+    ssum, ssq = stats_inputs(y)
+    gd, bd = gamma.to(DEV), beta.to(DEV)
+    sc, sh, mean, rstd = (torch.empty(C, device=DEV) for _ in range(4))
+    L.call("vae_bn_finalize", L.ptr(ssum), L.ptr(ssq), 1, C, 1, float(M), L.ptr(gd), L.ptr(bd), None, None, 0.1, 1e-5, 0,
+           L.ptr(sc), L.ptr(sh), L.ptr(mean), L.ptr(rstd), L.current_stream())
+    yd, wd, bbd = nhwc(y), w.view(Co, C).contiguous().to(DEV), b.to(DEV)
+    recon = torch.full((n, Co, H, W), float("nan"), device=DEV)
+    L.call("vae_head_fwd", L.ptr(yd), L.ptr(sc), L.ptr(sh), L.ptr(wd), L.ptr(bbd), L.ptr(recon), n, H, W, Co,
+           L.current_stream())
+    assert rel_l2(recon.cpu(), recon_ref.detach()) <= 1e-5
+    nb = L.call("vae_head_bwd_blocks", n, H, W)
+    ncols = (3 + Co) * 64
+    partial = torch.full((nb, ncols), float("nan"), device=DEV)
+    sums = torch.full((ncols,), float("nan"), device=DEV)
+    dy = torch.full((n, H, W, C), float("nan"), device=DEV, dtype=torch.bfloat16)
+    drd = dr.to(DEV)
+    L.call("vae_head_bwd", L.ptr(drd), L.ptr(recon), L.ptr(yd), L.ptr(sc), L.ptr(sh), L.ptr(mean), L.ptr(rstd),
+           L.ptr(wd), L.ptr(partial), L.ptr(sums), L.ptr(dy), n, H, W, Co, L.current_stream())
+    s = sums.cpu()
+    assert rel_l2(s[:64], gr.grad) <= 2e-5
+    assert rel_l2(s[64:128], br.grad) <= 2e-5
+    assert rel_l2(s[128:128 + Co * 64], wr.grad.view(-1)) <= 2e-5
+    assert rel_l2(s[128 + Co * 64:128 + Co * 64 + Co], bbr.grad) <= 2e-5
+    check_bf16(from_nhwc(dy), yr.grad, "head bwd", rtol=4e-3)
+
+
+# ------------------------------------------------------------------ small helpers
+def test_tanh_bwd_and_sum_partials(L):
+    g = torch.Generator().manual_seed(3)
+    rows, cols = 130, 4096
+    dx, h = bf(torch.randn(rows, cols, generator=g)), bf(torch.tanh(torch.randn(rows, cols, generator=g)))
+    ref = dx * (1 - h * h)
+    dxd, hd = dx.to(torch.bfloat16).to(DEV), h.to(torch.bfloat16).to(DEV)
+    nr = L.call("vae_tanh_bwd_rows", rows)
+    dpre = torch.empty(rows, cols, device=DEV, dtype=torch.bfloat16)
+    colp = torch.full((nr, cols), float("nan"), device=DEV)
+    L.call("vae_tanh_bwd", L.ptr(dxd), L.ptr(hd), L.ptr(dpre), L.ptr(colp), rows, cols, L.current_stream())
+    check_bf16(dpre.float().cpu(), ref, "tanh bwd")
+    out = torch.empty(cols, device=DEV)
+    L.call("vae_sum_partials", L.ptr(colp), nr, cols, L.ptr(out), 1.0, L.current_stream())
+    assert rel_l2(out.cpu(), ref.sum(0)) <= 1e-5

@@ -33,7 +33,31 @@ SIGNATURES = {
     "vae_convt2x2_fwd_gemm": (None, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "vae_convt2x2_dgrad_gemm": (None, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "vae_linear_gemm": (None, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "vae_conv3x3_c8_gemm": (None, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "vae_wgrad_ksplit": (c_int, [c_int, c_int, c_int, c_long]),
+    "vae_wgrad_gemm": (None, [P, P, P, c_int, c_int, c_long, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "vae_reduce_slabs": (None, [P, c_int, c_long, P, P, P, c_long, c_int, P]),
+    "vae_pack_bf16": (None, [P, P, P, P, c_long, P]),
+    "vae_bn_finalize": (None, [P, P, c_int, c_int, c_int, c_double, P, P, P, P, c_float, c_float, c_int,
+                               P, P, P, P, P]),
+    "vae_sum_partials": (None, [P, c_int, c_int, P, c_float, P]),
+    "vae_bn_act_fwd": (None, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_double, P, c_ulonglong,
+                              c_uint, c_uint, c_uint, P]),
+    "vae_bn_act_bwd_blocks": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "vae_bn_act_bwd": (None, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_double, P,
+                              c_ulonglong, c_uint, c_uint, c_uint, P]),
+    "vae_head_fwd": (None, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "vae_head_bwd_blocks": (c_int, [c_int, c_int, c_int]),
+    "vae_head_bwd": (None, [P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "vae_tanh_bwd_rows": (c_int, [c_int]),
+    "vae_tanh_bwd": (None, [P, P, P, P, c_int, c_int, P]),
+    "vae_nchw_to_nhwc8": (None, [P, P, c_int, c_int, c_int, c_int, P]),
 }
+
+
+def long4(*v):
+    """a C array of 4 longs (dims / strides arguments)."""
+    return (c_long * 4)(*v)
 
 _lib = None
 

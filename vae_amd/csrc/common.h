@@ -26,6 +26,10 @@ void set_error(const char* fmt, ...);
         }                                                                          \
     } while (0)
 
+// 256 bytes of zeros: the source of every padded / out-of-range row of a global_load_lds stage
+// (one private copy per translation unit; no relocatable device code needed).
+__device__ __attribute__((aligned(256))) static unsigned int g_zero_page[64];
+
 // ---------------------------------------------------------------- bf16
 typedef unsigned short bf16_t;  // raw bits
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;

@@ -1,0 +1,317 @@
+// bf16 MFMA weight-gradient GEMM, "NT" form:  dW[m][tap][n] = sum_k P[rowP(k,tap)][m] * Q[rowQ(k,tap)][n]
+//
+// K is the pixel (or batch) index and is the STRIDED dimension of both operands (activations
+// are NHWC: a row is one pixel, channels contiguous).  Tiles are staged row-wise into LDS
+// (global_load_lds, 16 B per lane, rows stay coalesced) and the K-contiguous MFMA fragments are
+// produced by the transposing LDS read ds_read_b64_tr_b16 -- no transposed copy of any
+// activation ever exists in memory.
+//
+// Row gathers (what makes it a conv weight gradient):
+//   G_PLAIN     rowP = rowQ = k                                      (linear layers)
+//   G_CONV3     rowP = k, rowQ = pixel k shifted by the tap, zero outside the image   (3x3 conv)
+//   G_CONVT     rowQ = k (input pixel), rowP = output pixel (2i+kh, 2j+kw)            (ConvTranspose k2s2)
+//   G_CONV3_C8  rowP = k, Q is the 8-channel-padded network input: one 16-byte chunk per
+//               tap, "tap" here selects taps 0-7 or 8-15 (taps >= 9 are zero)         (first conv)
+//
+// K is split over gridDim.z; every workgroup writes its fp32 partial tile to its own slab
+// ([split][m][tap][n], plain 16-byte stores, deterministic) and vae_reduce_slabs folds the slabs
+// into the gradient tensor in the reference layout.
+#include "common.h"
+#include "../../include/vae_hip.h"
+
+namespace vae {
+
+enum { G_PLAIN = 0, G_CONV3 = 1, G_CONVT = 2, G_CONV3_C8 = 3 };
+
+struct GemmNT {
+    const bf16_t* P;
+    const bf16_t* Q;
+    float* slab;
+    int M, N, Ktot, ldp, ldq;
+    int H, W, wshift, hshift;   // pixel grid of k (shifts >= 0 when powers of two, else -1)
+    int taps, kchunk;
+    long slab_stride;
+};
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+typedef __attribute__((address_space(3))) short4v* l4ptr_t;
+
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* base, int rowb, int k0, int col0, int lane) {
+    // lanes 16g..16g+15 fetch k rows k0+8g .. k0+8g+7 of columns col0..col0+15, transposed:
+    // lane (l&15) receives column col0+(l&15), elements = 8 consecutive k.
+    const int g = lane >> 4, t = lane & 15;
+    const unsigned char* a = base + (k0 + 8 * g + (t >> 2)) * rowb + (col0 + 4 * (t & 3)) * 2;
+    const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((l4ptr_t)(a));
+    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((l4ptr_t)(a + 4 * rowb));
+    typedef __attribute__((ext_vector_type(8))) short short8v;
+    const short8v v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int BM, int BN, int MODE>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNT p) {
+    constexpr int BK = 64;
+    constexpr int ROWP = BM * 2, ROWQ = BN * 2;          // LDS row bytes
+    constexpr int P_BYTES = BK * ROWP, Q_BYTES = BK * ROWQ, STAGE = P_BYTES + Q_BYTES;
+    constexpr int P_INSTR = P_BYTES / 1024 / 4, Q_INSTR = Q_BYTES / 1024 / 4;   // per wave
+    constexpr int P_CH = ROWP / 16, Q_CH = ROWQ / 16;    // 16-byte chunks per row
+    constexpr int TMw = BM / 2, TNw = BN / 2;            // wave tile (2 x 2 waves)
+    constexpr int FM = TMw / 16, FN = TNw / 16;
+
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave & 1, wm = wave >> 1;
+    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+    const int tap = blockIdx.z % p.taps, split = blockIdx.z / p.taps;
+    const int kbeg = split * p.kchunk;
+    const int kend = min(kbeg + p.kchunk, p.Ktot);
+    const bf16_t* zero = (const bf16_t*)g_zero_page;
+
+    int dh = 0, dw = 0;
+    if (MODE == G_CONV3) { dh = tap / 3 - 1; dw = tap % 3 - 1; }
+
+    auto split_hw = [&](int k, int& h, int& w, int& img) {
+        if (p.wshift >= 0 && p.hshift >= 0) {
+            w = k & (p.W - 1);
+            h = (k >> p.wshift) & (p.H - 1);
+            img = k >> (p.wshift + p.hshift);
+        } else {
+            w = k % p.W;
+            const int t = k / p.W;
+            h = t % p.H;
+            img = t / p.H;
+        }
+    };
+
+    auto stage = [&](int buf, int k0) {
+        unsigned char* pbase = smem + buf * STAGE;
+        unsigned char* qbase = pbase + P_BYTES;
+#pragma unroll
+        for (int i = 0; i < P_INSTR; ++i) {
+            const int t = wave + 4 * i;
+            const int row = t * (64 / P_CH) + lane / P_CH, chunk = lane % P_CH;
+            const int k = k0 + row;
+            const bf16_t* src = zero;
+            if (k < kend) {
+                long r = k;
+                if (MODE == G_CONVT) {
+                    int h, w, img;
+                    split_hw(k, h, w, img);
+                    r = ((long)img * 2 * p.H + 2 * h + (tap >> 1)) * (2 * p.W) + 2 * w + (tap & 1);
+                }
+                src = p.P + r * p.ldp + m0 + chunk * 8;
+            }
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(pbase + t * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < Q_INSTR; ++i) {
+            const int t = wave + 4 * i;
+            const int row = t * (64 / Q_CH) + lane / Q_CH, chunk = lane % Q_CH;
+            const int k = k0 + row;
+            const bf16_t* src = zero;
+            if (k < kend) {
+                if (MODE == G_CONV3) {
+                    int h, w, img;
+                    split_hw(k, h, w, img);
+                    if ((unsigned)(h + dh) < (unsigned)p.H && (unsigned)(w + dw) < (unsigned)p.W)
+                        src = p.Q + (long)(k + dh * p.W + dw) * p.ldq + n0 + chunk * 8;
+                } else if (MODE == G_CONV3_C8) {
+                    const int tp = tap * 8 + chunk;        // one 16-byte chunk = one tap's 8 channels
+                    int h, w, img;
+                    split_hw(k, h, w, img);
+                    const int eh = tp / 3 - 1, ew = tp % 3 - 1;
+                    if (tp < 9 && (unsigned)(h + eh) < (unsigned)p.H && (unsigned)(w + ew) < (unsigned)p.W)
+                        src = p.Q + (long)(k + eh * p.W + ew) * 8;
+                } else {
+                    src = p.Q + (long)k * p.ldq + n0 + chunk * 8;
+                }
+            }
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(qbase + t * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[FN][FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
+    if (nk > 0) stage(0, kbeg);
+    for (int ks = 0; ks < nk; ++ks) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (ks + 1 < nk) stage((ks + 1) & 1, kbeg + (ks + 1) * BK);
+        const unsigned char* pbase = smem + (ks & 1) * STAGE;
+        const unsigned char* qbase = pbase + P_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < BK / 32; ++kk) {
+            bf16x8 qa[FN], pb[FM];
+#pragma unroll
+            for (int i = 0; i < FN; ++i) qa[i] = tr_frag(qbase, ROWQ, kk * 32, wn * TNw + i * 16, lane);
+#pragma unroll
+            for (int j = 0; j < FM; ++j) pb[j] = tr_frag(pbase, ROWP, kk * 32, wm * TMw + j * 16, lane);
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+#pragma unroll
+                for (int j = 0; j < FM; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[i], pb[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // acc[i][j][r]: n = n0 + wn*TNw + i*16 + (lane>>4)*4 + r ; m = m0 + wm*TMw + j*16 + (lane&15)
+    float* out = p.slab + (long)split * p.slab_stride;
+#pragma unroll
+    for (int j = 0; j < FM; ++j) {
+        const int m = m0 + wm * TMw + j * 16 + (lane & 15);
+#pragma unroll
+        for (int i = 0; i < FN; ++i) {
+            const int n = n0 + wn * TNw + i * 16 + (lane >> 4) * 4;
+            if (m < p.M && n < p.N)
+                *(float4*)(out + ((long)m * p.taps + tap) * p.N + n) =
+                    make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        }
+    }
+}
+
+// out[e] (+)= sum_s slab[s][base + i0*s0 + i1*s1 + i2*s2 + i3*s3],  e = ((i0*D1 + i1)*D2 + i2)*D3 + i3
+struct IndexMap {
+    int d1, d2, d3;
+    long s0, s1, s2, s3, base;
+};
+
+__device__ __forceinline__ long map_index(const IndexMap& mp, long e) {
+    const int i3 = (int)(e % mp.d3);
+    long t = e / mp.d3;
+    const int i2 = (int)(t % mp.d2);
+    t /= mp.d2;
+    const int i1 = (int)(t % mp.d1);
+    const long i0 = t / mp.d1;
+    return mp.base + i0 * mp.s0 + i1 * mp.s1 + i2 * mp.s2 + i3 * mp.s3;
+}
+
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slab, int nsplit,
+                                                           long slab_stride, float* __restrict__ out,
+                                                           long n, IndexMap mp, int accumulate) {
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const long src = map_index(mp, e);
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += slab[(long)k * slab_stride + src];
+        out[e] = accumulate ? out[e] + s : s;
+    }
+}
+
+__global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst,
+                                                        long n, IndexMap mp) {
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x)
+        dst[map_index(mp, e)] = f2bf(src[e]);
+}
+
+static int ilog2_exact(int v) {
+    if (v <= 0 || (v & (v - 1))) return -1;
+    int s = 0;
+    while ((1 << s) < v) ++s;
+    return s;
+}
+
+template <int MODE>
+static int launch_nt(const GemmNT& p, int nsplit, hipStream_t s) {
+    const bool m128 = p.M % 128 == 0, n128 = p.N % 128 == 0;
+    dim3 block(256);
+#define GO(BM_, BN_)                                                                          \
+    {                                                                                         \
+        dim3 grid(p.N / BN_, p.M / BM_, p.taps * nsplit);                                     \
+        hipLaunchKernelGGL((gemm_nt_kernel<BM_, BN_, MODE>), grid, block, 0, s, p);           \
+    }
+    if (m128 && n128) GO(128, 128)
+    else if (m128) GO(128, 64)
+    else if (n128) GO(64, 128)
+    else GO(64, 64)
+#undef GO
+    VAE_LAUNCH_CHECK("gemm_nt_kernel");
+    return 0;
+}
+
+}  // namespace vae
+
+using namespace vae;
+
+extern "C" int vae_wgrad_ksplit(int M, int N, int taps, long Ktot) {
+    // aim at ~1024 workgroups, at least 256 k rows each
+    long tiles = (long)((M + 127) / 128) * ((N + 127) / 128) * taps;
+    if (M % 128) tiles = tiles * 1;   // 64-wide tiles: count stays a lower bound
+    long s = (1024 + tiles - 1) / tiles;
+    const long maxs = (Ktot + 255) / 256;
+    if (s > maxs) s = maxs;
+    if (s < 1) s = 1;
+    if (s > 256) s = 256;
+    return (int)s;
+}
+
+extern "C" int vae_wgrad_gemm(const void* P, const void* Q, float* slab, int M, int N, long Ktot, int ldp,
+                              int ldq, int mode, int H, int W, int nsplit, void* stream) {
+    VAE_CHECK(P && Q && slab, "vae_wgrad_gemm: null pointer");
+    VAE_CHECK(M > 0 && N > 0 && Ktot > 0 && Ktot < (1L << 31) && nsplit > 0, "vae_wgrad_gemm: bad sizes M=%d N=%d K=%ld S=%d", M, N, Ktot, nsplit);
+    VAE_CHECK(M % 64 == 0 && N % 64 == 0, "vae_wgrad_gemm: M=%d and N=%d must be multiples of 64", M, N);
+    VAE_CHECK((((uintptr_t)P | (uintptr_t)Q | (uintptr_t)slab) & 15) == 0 && ldp % 8 == 0 && ldq % 8 == 0,
+              "vae_wgrad_gemm: operands must be 16-byte aligned with row strides a multiple of 8");
+    GemmNT p = {};
+    p.P = (const bf16_t*)P; p.Q = (const bf16_t*)Q; p.slab = slab;
+    p.M = M; p.N = N; p.Ktot = (int)Ktot; p.ldp = ldp; p.ldq = ldq;
+    p.H = H; p.W = W; p.wshift = ilog2_exact(W); p.hshift = ilog2_exact(H);
+    const long chunk = ((Ktot + nsplit - 1) / nsplit + 63) / 64 * 64;
+    p.kchunk = (int)chunk;
+    VAE_CHECK((long)(nsplit - 1) * chunk < Ktot, "vae_wgrad_gemm: nsplit=%d leaves empty splits for K=%ld", nsplit, Ktot);
+    hipStream_t s = (hipStream_t)stream;
+    switch (mode) {
+        case VAE_WGRAD_PLAIN: p.taps = 1; p.slab_stride = (long)M * N; return launch_nt<G_PLAIN>(p, nsplit, s);
+        case VAE_WGRAD_CONV3:
+            VAE_CHECK(H > 0 && W > 0 && Ktot % ((long)H * W) == 0, "vae_wgrad_gemm: K=%ld is not a whole number of %dx%d images", Ktot, H, W);
+            p.taps = 9; p.slab_stride = 9L * M * N; return launch_nt<G_CONV3>(p, nsplit, s);
+        case VAE_WGRAD_CONVT:
+            VAE_CHECK(H > 0 && W > 0 && Ktot % ((long)H * W) == 0, "vae_wgrad_gemm: K=%ld is not a whole number of %dx%d images", Ktot, H, W);
+            p.taps = 4; p.slab_stride = 4L * M * N; return launch_nt<G_CONVT>(p, nsplit, s);
+        case VAE_WGRAD_CONV3_C8:
+            VAE_CHECK(N == 64 && H > 0 && W > 0 && Ktot % ((long)H * W) == 0, "vae_wgrad_gemm: the 8-channel input mode needs N == 64 (8 taps x 8 channels)");
+            p.taps = 2; p.slab_stride = 2L * M * N; return launch_nt<G_CONV3_C8>(p, nsplit, s);
+        default: VAE_CHECK(false, "vae_wgrad_gemm: unknown mode %d", mode);
+    }
+    return 0;
+}
+
+static int make_map(IndexMap& mp, const long* dims, const long* strides, long base, const char* who) {
+    VAE_CHECK(dims && strides, "%s: null dims/strides", who);
+    VAE_CHECK(dims[0] > 0 && dims[1] > 0 && dims[2] > 0 && dims[3] > 0 && dims[1] < (1L << 31) &&
+                  dims[2] < (1L << 31) && dims[3] < (1L << 31), "%s: bad dims", who);
+    mp.d1 = (int)dims[1]; mp.d2 = (int)dims[2]; mp.d3 = (int)dims[3];
+    mp.s0 = strides[0]; mp.s1 = strides[1]; mp.s2 = strides[2]; mp.s3 = strides[3];
+    mp.base = base;
+    return 0;
+}
+
+extern "C" int vae_reduce_slabs(const float* slab, int nsplit, long slab_stride, float* out, const long* dims4,
+                                const long* strides4, long base, int accumulate, void* stream) {
+    VAE_CHECK(slab && out && nsplit > 0, "vae_reduce_slabs: bad arguments");
+    IndexMap mp;
+    if (int e = make_map(mp, dims4, strides4, base, "vae_reduce_slabs")) return e;
+    const long n = dims4[0] * dims4[1] * dims4[2] * dims4[3];
+    const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, slab, nsplit,
+                       slab_stride, out, n, mp, accumulate);
+    VAE_LAUNCH_CHECK("reduce_slabs_kernel");
+    return 0;
+}
+
+extern "C" int vae_pack_bf16(const float* src, void* dst, const long* dims4, const long* strides4, long base,
+                             void* stream) {
+    VAE_CHECK(src && dst, "vae_pack_bf16: null pointer");
+    IndexMap mp;
+    if (int e = make_map(mp, dims4, strides4, base, "vae_pack_bf16")) return e;
+    const long n = dims4[0] * dims4[1] * dims4[2] * dims4[3];
+    const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL(pack_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n, mp);
+    VAE_LAUNCH_CHECK("pack_bf16_kernel");
+    return 0;
+}

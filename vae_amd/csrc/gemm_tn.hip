@@ -9,6 +9,9 @@
 //                  zero page when it falls in the padding              (3x3 s1 p1 conv fwd and dgrad)
 //   A_CONVT_DGRAD  row m = input pixel (img,i,j); K = (tap, c): output pixel (2i+kh, 2j+kw)
 //                                                                      (ConvTranspose2d k2 s2 dgrad)
+//   A_CONV3_C8     the network input padded to 8 channels (16 B per pixel): every 16-byte chunk
+//                  of a row is ONE tap's pixel; K = 16 taps x 8 channels, taps >= 9 are zero
+//                                                                      (first conv, Cin <= 8)
 // Tiles are staged global -> LDS with global_load_lds (16 B per lane, no VGPR round trip);
 // the LDS image is lane-linear, the XOR bank swizzle is applied to the per-lane SOURCE chunk
 // and again on the fragment read.  Double-buffered, one barrier per K-step.
@@ -22,9 +25,7 @@
 
 namespace vae {
 
-__device__ __attribute__((aligned(256))) unsigned int g_zero_page[64];
-
-enum { A_PLAIN = 0, A_CONV3 = 1, A_CONVT_DGRAD = 2 };
+enum { A_PLAIN = 0, A_CONV3 = 1, A_CONVT_DGRAD = 2, A_CONV3_C8 = 3 };
 enum { E_BF16 = 0, E_CONVT = 1, E_F32_SPLIT = 2, E_TANH_BF16 = 3, E_F32 = 4 };
 
 struct GemmTN {
@@ -70,6 +71,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
     const bf16_t* zero = (const bf16_t*)g_zero_page;
     long a_off[A_INSTR];
     int a_hw[A_INSTR];
+    int a_chunk[A_INSTR];
     bool a_ok[A_INSTR];
 #pragma unroll
     for (int i = 0; i < A_INSTR; ++i) {
@@ -78,7 +80,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
         const int m = m0 + row;
         a_ok[i] = m < p.M;
         a_hw[i] = 0;
-        if (AMODE == A_PLAIN) {
+        a_chunk[i] = chunk;
+        if (AMODE == A_CONV3_C8) {
+            const int w = m % p.W, t = m / p.W, h = t % p.H, img = t / p.H;
+            a_off[i] = (((long)img * p.H + h) * p.W + w) * 8;
+            a_hw[i] = (h << 16) | w;
+        } else if (AMODE == A_PLAIN) {
             a_off[i] = (long)m * p.lda + chunk * 8;
         } else if (AMODE == A_CONV3) {
             const int w = m % p.W, t = m / p.W, h = t % p.H, img = t / p.H;
@@ -99,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
         b_ok[i] = n < p.N;
         b_off[i] = (long)n * p.K + chunk * 8;
     }
-    const int cpt = (AMODE == A_PLAIN) ? 1 : p.C / BK;   // K-steps per tap
+    const int cpt = (AMODE == A_PLAIN || AMODE == A_CONV3_C8) ? 1 : p.C / BK;   // K-steps per tap
 
     auto stage = [&](int buf, int ks) {
         unsigned char* abase = smem + buf * STAGE;
@@ -107,6 +114,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
         int dh = 0, dw = 0;
         if (AMODE == A_PLAIN) {
             tap_off = (long)ks * BK;
+        } else if (AMODE == A_CONV3_C8) {
+            tap_off = 0;
         } else if (AMODE == A_CONV3) {
             const int tap = ks / cpt, c0 = (ks - tap * cpt) * BK;
             dh = tap / 3 - 1;
@@ -122,6 +131,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
             if (AMODE == A_CONV3) {
                 const int h = (a_hw[i] >> 16) + dh, w = (a_hw[i] & 0xFFFF) + dw;
                 ok = ok && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
+            }
+            if (AMODE == A_CONV3_C8) {
+                const int tp = ks * 8 + a_chunk[i];
+                const int eh = tp / 3 - 1, ew = tp % 3 - 1;
+                const int h = (a_hw[i] >> 16) + eh, w = (a_hw[i] & 0xFFFF) + ew;
+                ok = ok && tp < 9 && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
+                tap_off = ((long)eh * p.W + ew) * 8;
             }
             const bf16_t* src = ok ? p.A + a_off[i] + tap_off : zero;
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(abase + (wave + 4 * i) * 1024), 16, 0, 0);
@@ -302,6 +318,19 @@ extern "C" int vae_conv3x3_gemm(const void* x, const void* w_packed, const float
     p.M = n_img * H * W; p.N = Cout; p.K = 9 * Cin; p.H = H; p.W = W; p.C = Cin; p.ldo = Cout;
     if (int e = check_common(p, 64, "vae_conv3x3_gemm")) return e;
     return launch_bk64<A_CONV3, E_BF16>(p, (hipStream_t)stream);
+}
+
+extern "C" int vae_conv3x3_c8_gemm(const void* x8, const void* w_packed, const float* bias, void* y,
+                                   float* stat_sum, float* stat_sq, int n_img, int H, int W, int Cout,
+                                   void* stream) {
+    GemmTN p = {};
+    p.A = (const bf16_t*)x8; p.B = (const bf16_t*)w_packed; p.bias = bias; p.out = y;
+    p.stat_sum = stat_sum; p.stat_sq = stat_sq;
+    VAE_CHECK(n_img > 0 && H > 0 && W > 0 && (long)n_img * H * W < (1L << 31) && H < 65536 && W < 65536,
+              "vae_conv3x3_c8_gemm: bad geometry n=%d H=%d W=%d", n_img, H, W);
+    p.M = n_img * H * W; p.N = Cout; p.K = 128; p.H = H; p.W = W; p.C = 8; p.ldo = Cout;
+    if (int e = check_common(p, 64, "vae_conv3x3_c8_gemm")) return e;
+    return launch_bk64<A_CONV3_C8, E_BF16>(p, (hipStream_t)stream);
 }
 
 extern "C" int vae_convt2x2_fwd_gemm(const void* x, const void* w_packed, const float* bias, void* y,

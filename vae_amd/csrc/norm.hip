@@ -1,0 +1,639 @@
+// HBM-bound glue of the conv VAE: BatchNorm (train/eval) + ReLU + Dropout + MaxPool2d(2)
+// forward and backward, the 1x1 head + sigmoid, tanh backward, layout conversion, and the
+// small partial-sum reducers.  Activations are NHWC bf16; one thread owns 8 consecutive
+// channels (one 16-byte access) of a pixel, or of a 2x2 pooling window.
+//
+//   forward : a = relu(y*scale + shift); d = keep ? a/(1-p) : 0; out = d or max over the window
+//   backward: the forward is RECOMPUTED from the saved pre-norm tensor y (no mask, no argmax and
+//             no full-resolution activation is stored): pass 1 reduces sum(g) and sum(g*xhat) per
+//             channel, pass 2 writes dy = scale * (g - mean(g) - xhat * mean(g*xhat)).
+#include "common.h"
+#include "../../include/vae_hip.h"
+
+namespace vae {
+
+struct DropCfg {
+    int enabled;
+    uint32_t thr;
+    float inv_keep;
+    PhiloxKey key;
+    const uint8_t* mask;   // optional injected keep-mask, same [pixel][C] layout as y
+};
+
+__device__ __forceinline__ void load8(const bf16_t* p, float v[8]) {
+    const uint4 u = *(const uint4*)p;
+    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[2 * i] = __uint_as_float(w[i] << 16);
+        v[2 * i + 1] = __uint_as_float(w[i] & 0xFFFF0000u);
+    }
+}
+__device__ __forceinline__ void store8(bf16_t* p, const float v[8]) {
+    *(uint4*)p = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+}
+__device__ __forceinline__ void load8f(const float* p, float v[8]) {
+    const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+
+// keep flags of the 8 elements idx0..idx0+7 (idx0 % 8 == 0) of the dropout stream
+__device__ __forceinline__ void keep8(const DropCfg& d, long idx0, bool keep[8]) {
+    if (d.mask) {
+        const uint2 m = *(const uint2*)(d.mask + idx0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            keep[i] = (m.x >> (8 * i)) & 0xFF;
+            keep[4 + i] = (m.y >> (8 * i)) & 0xFF;
+        }
+    } else {
+        uint32_t w[4];
+        philox_block(d.key, (uint32_t)(idx0 >> 2), w);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) keep[i] = (w[i] >> 8) >= d.thr;
+        philox_block(d.key, (uint32_t)(idx0 >> 2) + 1u, w);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) keep[4 + i] = (w[i] >> 8) >= d.thr;
+    }
+}
+
+// d = dropout(relu(y*sc + sh)) for 8 channels; pos[i] = relu active, kp[i] = kept
+__device__ __forceinline__ void act8(const float y[8], const float sc[8], const float sh[8], const DropCfg& d,
+                                     long idx0, float out[8], bool pos[8], bool kp[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) kp[i] = true;
+    if (d.enabled) keep8(d, idx0, kp);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float a = y[i] * sc[i] + sh[i];
+        pos[i] = a > 0.f;
+        float v = pos[i] ? a : 0.f;
+        if (d.enabled) v = kp[i] ? v * d.inv_keep : 0.f;
+        out[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// batch statistics -> scale / shift / mean / rstd (+ running stats), one pass over the
+// per-workgroup partials left by the GEMM epilogue.  grid = ceil(C/64), block = 1024.
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(
+    const float* __restrict__ psum, const float* __restrict__ psq, int rows, int C, int fold, double count,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ running_mean,
+    float* __restrict__ running_var, float momentum, float eps, int use_running, float* __restrict__ scale,
+    float* __restrict__ shift, float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+    __shared__ double red[2][16][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    double s = 0.0, q = 0.0;
+    if (!use_running && c < C) {
+        const int ncols = fold * C;
+        for (int r = rg; r < rows; r += 16)
+            for (int t = 0; t < fold; ++t) {
+                s += (double)psum[(long)r * ncols + t * C + c];
+                q += (double)psq[(long)r * ncols + t * C + c];
+            }
+    }
+    red[0][rg][cl] = s;
+    red[1][rg][cl] = q;
+    __syncthreads();
+    if (rg == 0 && c < C) {
+        float mean, var;
+        if (use_running) {
+            mean = running_mean[c];
+            var = running_var[c];
+        } else {
+#pragma unroll
+            for (int i = 1; i < 16; ++i) { s += red[0][i][cl]; q += red[1][i][cl]; }
+            const double m = s / count;
+            double v = q / count - m * m;
+            if (v < 0.0) v = 0.0;
+            mean = (float)m;
+            var = (float)v;
+            if (running_mean) {
+                const double unb = count > 1.0 ? v * count / (count - 1.0) : v;
+                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+                running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+            }
+        }
+        const float rstd = 1.0f / sqrtf(var + eps);
+        const float sc = gamma[c] * rstd;
+        scale[c] = sc;
+        shift[c] = beta[c] - mean * sc;
+        mean_out[c] = mean;
+        rstd_out[c] = rstd;
+    }
+}
+
+// out[j] = sum_r partial[r][j]; grid = ceil(ncols/64), block = 1024
+__global__ __launch_bounds__(1024) void sum_partials_kernel(const float* __restrict__ partial, int rows, int ncols,
+                                                            float* __restrict__ out, float mul) {
+    __shared__ double red[16][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    double s = 0.0;
+    if (c < ncols)
+        for (int r = rg; r < rows; r += 16) s += (double)partial[(long)r * ncols + c];
+    red[rg][cl] = s;
+    __syncthreads();
+    if (rg == 0 && c < ncols) {
+#pragma unroll
+        for (int i = 1; i < 16; ++i) s += red[i][cl];
+        out[c] = (float)(s * (double)mul);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+struct ActGeom {
+    int n_img, H, W, C;   // full-resolution geometry of y
+    int pool;
+};
+
+template <bool POOL>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16_t* __restrict__ y, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, bf16_t* __restrict__ out,
+                                                         ActGeom g, DropCfg d) {
+    const int cgs = g.C >> 3;
+    const long npos = POOL ? (long)g.n_img * (g.H >> 1) * (g.W >> 1) : (long)g.n_img * g.H * g.W;
+    const long total = npos * cgs;
+    for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long)gridDim.x * blockDim.x) {
+        const int cg = (int)(id % cgs);
+        const long pos = id / cgs;
+        const int c0 = cg * 8;
+        float sc[8], sh[8];
+        load8f(scale + c0, sc);
+        load8f(shift + c0, sh);
+        float o[8];
+        bool ps[8], kp[8];
+        if (!POOL) {
+            float v[8];
+            load8(y + pos * g.C + c0, v);
+            act8(v, sc, sh, d, pos * g.C + c0, o, ps, kp);
+        } else {
+            const int wo = (int)(pos % (g.W >> 1));
+            const long t = pos / (g.W >> 1);
+            const int ho = (int)(t % (g.H >> 1));
+            const long img = t / (g.H >> 1);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const long pix = (img * g.H + 2 * ho + (k >> 1)) * g.W + 2 * wo + (k & 1);
+                float v[8], a[8];
+                load8(y + pix * g.C + c0, v);
+                act8(v, sc, sh, d, pix * g.C + c0, a, ps, kp);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] = fmaxf(o[i], a[i]);
+            }
+        }
+        store8(out + pos * g.C + c0, o);
+    }
+}
+
+// PASS 0: reduce sum(g*xhat), sum(g) per channel into partial[block][2][C];  PASS 1: write dy.
+template <bool POOL, int PASS>
+__global__ __launch_bounds__(256) void bn_act_bwd_kernel(const bf16_t* __restrict__ gin, const bf16_t* __restrict__ y,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         const float* __restrict__ sums, float inv_count,
+                                                         float* __restrict__ partial, bf16_t* __restrict__ dy,
+                                                         ActGeom g, DropCfg d) {
+    __shared__ float red[2][256][8];
+    const int cgs = g.C >> 3;
+    const long npos = POOL ? (long)g.n_img * (g.H >> 1) * (g.W >> 1) : (long)g.n_img * g.H * g.W;
+    const long total = npos * cgs;
+    const int cg = threadIdx.x % cgs;       // fixed per thread: block and grid strides are multiples of cgs
+    const int c0 = cg * 8;
+    float sc[8], sh[8], mu[8], rs[8], c1[8], c2[8];
+    load8f(scale + c0, sc);
+    load8f(shift + c0, sh);
+    load8f(mean + c0, mu);
+    load8f(rstd + c0, rs);
+    if (PASS == 1) {
+        load8f(sums + c0, c2);            // sum(g*xhat)
+        load8f(sums + g.C + c0, c1);      // sum(g)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { c1[i] *= inv_count; c2[i] *= inv_count; }
+    }
+    float a_gx[8], a_g[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a_gx[i] = a_g[i] = 0.f;
+
+    for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long)gridDim.x * blockDim.x) {
+        const long pos = id / cgs;
+        float gi[8];
+        load8(gin + pos * g.C + c0, gi);
+        if (!POOL) {
+            float v[8], a[8];
+            bool ps[8], kp[8];
+            load8(y + pos * g.C + c0, v);
+            act8(v, sc, sh, d, pos * g.C + c0, a, ps, kp);
+            float o[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float gg = ps[i] ? gi[i] : 0.f;
+                if (d.enabled) gg = kp[i] ? gg * d.inv_keep : 0.f;
+                const float xh = (v[i] - mu[i]) * rs[i];
+                if (PASS == 0) { a_gx[i] += gg * xh; a_g[i] += gg; }
+                else o[i] = sc[i] * (gg - c1[i] - xh * c2[i]);
+            }
+            if (PASS == 1) store8(dy + pos * g.C + c0, o);
+        } else {
+            const int wo = (int)(pos % (g.W >> 1));
+            const long t = pos / (g.W >> 1);
+            const int ho = (int)(t % (g.H >> 1));
+            const long img = t / (g.H >> 1);
+            float v[4][8], a[4][8];
+            bool ps[4][8], kp[4][8];
+            long pix[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                pix[k] = (img * g.H + 2 * ho + (k >> 1)) * g.W + 2 * wo + (k & 1);
+                load8(y + pix[k] * g.C + c0, v[k]);
+                act8(v[k], sc, sh, d, pix[k] * g.C + c0, a[k], ps[k], kp[k]);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                // first maximum in scan order wins (strict >), as in MaxPool2d
+                int arg = 0;
+                float best = a[0][i];
+#pragma unroll
+                for (int k = 1; k < 4; ++k)
+                    if (a[k][i] > best) { best = a[k][i]; arg = k; }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float gg = (k == arg && ps[k][i]) ? gi[i] : 0.f;
+                    if (d.enabled) gg = kp[k][i] ? gg * d.inv_keep : 0.f;
+                    const float xh = (v[k][i] - mu[i]) * rs[i];
+                    if (PASS == 0) { a_gx[i] += gg * xh; a_g[i] += gg; }
+                    else a[k][i] = sc[i] * (gg - c1[i] - xh * c2[i]);
+                }
+            }
+            if (PASS == 1) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) store8(dy + pix[k] * g.C + c0, a[k]);
+            }
+        }
+    }
+    if (PASS == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { red[0][threadIdx.x][i] = a_gx[i]; red[1][threadIdx.x][i] = a_g[i]; }
+        __syncthreads();
+        // threads 0 .. 2*C-1 each fold one (row, channel) column over the pixel lanes
+        for (int j = threadIdx.x; j < 2 * g.C; j += blockDim.x) {
+            const int row = j / g.C, c = j % g.C;
+            float s = 0.f;
+            for (int t = (c >> 3); t < 256; t += cgs) s += red[row][t][c & 7];
+            partial[(long)blockIdx.x * 2 * g.C + j] = s;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// 1x1 head + sigmoid fused with the last BatchNorm + ReLU.  8 lanes share one pixel.
+//   a = relu(y*scale + shift) ; logit[o] = sum_c a[c] w[o][c] + b[o] ; recon = sigmoid(logit)
+template <int CO>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const bf16_t* __restrict__ y, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, const float* __restrict__ w,
+                                                       const float* __restrict__ b, float* __restrict__ recon,
+                                                       long npix, int hw) {
+    const int sub = threadIdx.x & 7, c0 = sub * 8;
+    float sc[8], sh[8], wv[CO][8];
+    load8f(scale + c0, sc);
+    load8f(shift + c0, sh);
+#pragma unroll
+    for (int o = 0; o < CO; ++o) load8f(w + o * 64 + c0, wv[o]);
+    const long stride = (long)gridDim.x * (blockDim.x >> 3);
+    const long iters = (npix + stride - 1) / stride;
+    for (long it = 0; it < iters; ++it) {
+        const long pix = it * stride + (long)blockIdx.x * (blockDim.x >> 3) + (threadIdx.x >> 3);
+        const bool ok = pix < npix;
+        float v[8], acc[CO];
+#pragma unroll
+        for (int o = 0; o < CO; ++o) acc[o] = 0.f;
+        if (ok) {
+            load8(y + pix * 64 + c0, v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float a = fmaxf(v[i] * sc[i] + sh[i], 0.f);
+#pragma unroll
+                for (int o = 0; o < CO; ++o) acc[o] += a * wv[o][i];
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < CO; ++o) {
+            acc[o] += __shfl_xor(acc[o], 1, 64);
+            acc[o] += __shfl_xor(acc[o], 2, 64);
+            acc[o] += __shfl_xor(acc[o], 4, 64);
+        }
+        if (ok && sub < CO) {
+            float l = 0.f;
+#pragma unroll
+            for (int o = 0; o < CO; ++o) if (sub == o) l = acc[o] + b[o];
+            const long img = pix / hw, p = pix % hw;
+            recon[(img * CO + sub) * hw + p] = 1.f / (1.f + expf(-l));
+        }
+    }
+}
+
+// PASS 0: partial[block] = [sum(g*xhat)(64) | sum(g)(64) | dW[CO][64] | db[CO] (padded to 64)]
+// PASS 1: dy = scale * (g - mean(g) - xhat*mean(g*xhat))
+template <int CO, int PASS>
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ drecon, const float* __restrict__ recon,
+                                                       const bf16_t* __restrict__ y, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd, const float* __restrict__ w,
+                                                       const float* __restrict__ sums, float inv_count,
+                                                       float* __restrict__ partial, bf16_t* __restrict__ dy, long npix,
+                                                       int hw) {
+    constexpr int ROWS = 3 + CO;
+    __shared__ float red[ROWS][32][64 + 1];
+    const int sub = threadIdx.x & 7, c0 = sub * 8, pl = threadIdx.x >> 3;
+    float sc[8], sh[8], mu[8], rs[8], wv[CO][8], c1[8], c2[8];
+    load8f(scale + c0, sc);
+    load8f(shift + c0, sh);
+    load8f(mean + c0, mu);
+    load8f(rstd + c0, rs);
+#pragma unroll
+    for (int o = 0; o < CO; ++o) load8f(w + o * 64 + c0, wv[o]);
+    if (PASS == 1) {
+        load8f(sums + c0, c2);
+        load8f(sums + 64 + c0, c1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { c1[i] *= inv_count; c2[i] *= inv_count; }
+    }
+    float a_gx[8], a_g[8], a_w[CO][8], a_b[CO];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        a_gx[i] = a_g[i] = 0.f;
+#pragma unroll
+        for (int o = 0; o < CO; ++o) a_w[o][i] = 0.f;
+    }
+#pragma unroll
+    for (int o = 0; o < CO; ++o) a_b[o] = 0.f;
+
+    const long stride = (long)gridDim.x * 32;
+    for (long pix = (long)blockIdx.x * 32 + pl; pix < npix; pix += stride) {
+        const long img = pix / hw, p = pix % hw;
+        float dl[CO];
+#pragma unroll
+        for (int o = 0; o < CO; ++o) {
+            const long e = (img * CO + o) * hw + p;
+            const float r = recon[e];
+            dl[o] = drecon[e] * r * (1.f - r);
+        }
+        float v[8], o8[8];
+        load8(y + pix * 64 + c0, v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float a = v[i] * sc[i] + sh[i];
+            const bool pos = a > 0.f;
+            float da = 0.f;
+#pragma unroll
+            for (int o = 0; o < CO; ++o) da += dl[o] * wv[o][i];
+            const float gg = pos ? da : 0.f;
+            const float xh = (v[i] - mu[i]) * rs[i];
+            if (PASS == 0) {
+                a_gx[i] += gg * xh;
+                a_g[i] += gg;
+                const float ar = pos ? a : 0.f;
+#pragma unroll
+                for (int o = 0; o < CO; ++o) a_w[o][i] += dl[o] * ar;
+            } else {
+                o8[i] = sc[i] * (gg - c1[i] - xh * c2[i]);
+            }
+        }
+        if (PASS == 0 && sub == 0) {
+#pragma unroll
+            for (int o = 0; o < CO; ++o) a_b[o] += dl[o];
+        }
+        if (PASS == 1) store8(dy + pix * 64 + c0, o8);
+    }
+    if (PASS == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            red[0][pl][c0 + i] = a_gx[i];
+            red[1][pl][c0 + i] = a_g[i];
+#pragma unroll
+            for (int o = 0; o < CO; ++o) red[2 + o][pl][c0 + i] = a_w[o][i];
+        }
+        if (sub == 0) {
+#pragma unroll
+            for (int o = 0; o < CO; ++o) red[2 + CO][pl][o] = a_b[o];
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < ROWS * 64; j += blockDim.x) {
+            const int row = j >> 6, c = j & 63;
+            float s = 0.f;
+            if (row < 2 + CO || c < CO)
+                for (int t = 0; t < 32; ++t) s += red[row][t][c];
+            partial[(long)blockIdx.x * ROWS * 64 + j] = s;
+        }
+    }
+}
+
+// d(pre-tanh) = dx * (1 - h^2); also per-column partial sums (the fc_up bias gradient)
+__global__ __launch_bounds__(256) void tanh_bwd_kernel(const bf16_t* __restrict__ dx, const bf16_t* __restrict__ h,
+                                                       bf16_t* __restrict__ dpre, float* __restrict__ colpartial,
+                                                       int rows, int cols) {
+    // one thread per 8 columns, grid.y strides over rows
+    const int c0 = (blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (c0 >= cols) return;
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    for (int r = blockIdx.y; r < rows; r += gridDim.y) {
+        float a[8], b[8], o[8];
+        load8(dx + (long)r * cols + c0, a);
+        load8(h + (long)r * cols + c0, b);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            o[i] = a[i] * (1.f - b[i] * b[i]);
+            acc[i] += o[i];
+        }
+        store8(dpre + (long)r * cols + c0, o);
+    }
+    *(float4*)(colpartial + (long)blockIdx.y * cols + c0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    *(float4*)(colpartial + (long)blockIdx.y * cols + c0 + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+}
+
+// network input NCHW fp32 (C <= 8) -> NHWC bf16 padded to 8 channels
+__global__ __launch_bounds__(256) void nchw_to_nhwc8_kernel(const float* __restrict__ x, bf16_t* __restrict__ out,
+                                                            long npix, int C, int hw) {
+    for (long pix = (long)blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += (long)gridDim.x * blockDim.x) {
+        const long img = pix / hw, p = pix % hw;
+        float v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = c < C ? x[(img * C + c) * hw + p] : 0.f;
+        store8(out + pix * 8, v);
+    }
+}
+
+static DropCfg make_drop(double p_drop, const void* mask, unsigned long long seed, unsigned step, unsigned stream_id,
+                         unsigned rank) {
+    DropCfg d = {};
+    d.enabled = p_drop > 0.0;
+    d.thr = vae_dropout_threshold(p_drop);
+    d.inv_keep = (float)(1.0 / (1.0 - p_drop));
+    d.key.seed_lo = (uint32_t)seed; d.key.seed_hi = (uint32_t)(seed >> 32);
+    d.key.step = step; d.key.stream = stream_id; d.key.rank = rank;
+    d.mask = (const uint8_t*)mask;
+    return d;
+}
+
+static int check_geom(const char* who, int n_img, int H, int W, int C, int pool) {
+    VAE_CHECK(n_img > 0 && H > 0 && W > 0 && C > 0, "%s: bad geometry n=%d H=%d W=%d C=%d", who, n_img, H, W, C);
+    VAE_CHECK(C % 8 == 0 && 256 % (C / 8) == 0 && C <= 2048, "%s: C=%d must be 8 * a divisor of 256", who, C);
+    VAE_CHECK(!pool || (H % 2 == 0 && W % 2 == 0), "%s: pooling needs even H, W (got %dx%d)", who, H, W);
+    return 0;
+}
+
+static int elem_grid(long items) {
+    long b = (items + 255) / 256;
+    if (b < 1) b = 1;
+    if (b > 2048) b = 2048;
+    return (int)b;
+}
+
+}  // namespace vae
+
+using namespace vae;
+
+extern "C" int vae_bn_finalize(const float* stat_sum, const float* stat_sq, int rows, int C, int fold, double count,
+                               const float* gamma, const float* beta, float* running_mean, float* running_var,
+                               float momentum, float eps, int use_running, float* scale, float* shift, float* mean,
+                               float* rstd, void* stream) {
+    VAE_CHECK(gamma && beta && scale && shift && mean && rstd, "vae_bn_finalize: null pointer");
+    VAE_CHECK(use_running ? (running_mean && running_var) : (stat_sum && stat_sq && rows > 0 && count > 0),
+              "vae_bn_finalize: missing statistics input");
+    VAE_CHECK(C > 0 && fold > 0, "vae_bn_finalize: bad C=%d fold=%d", C, fold);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, stat_sum, stat_sq,
+                       rows, C, fold, count, gamma, beta, running_mean, running_var, momentum, eps, use_running, scale,
+                       shift, mean, rstd);
+    VAE_LAUNCH_CHECK("bn_finalize_kernel");
+    return 0;
+}
+
+extern "C" int vae_sum_partials(const float* partial, int rows, int ncols, float* out, float mul, void* stream) {
+    VAE_CHECK(partial && out && rows > 0 && ncols > 0, "vae_sum_partials: bad arguments");
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((ncols + 63) / 64), dim3(1024), 0, (hipStream_t)stream, partial, rows,
+                       ncols, out, mul);
+    VAE_LAUNCH_CHECK("sum_partials_kernel");
+    return 0;
+}
+
+extern "C" int vae_bn_act_fwd(const void* y, const float* scale, const float* shift, void* out, int n_img, int H, int W,
+                              int C, int pool, double p_drop, const void* keep_mask, unsigned long long seed,
+                              unsigned step, unsigned stream_id, unsigned rank, void* stream) {
+    VAE_CHECK(y && scale && shift && out, "vae_bn_act_fwd: null pointer");
+    if (int e = check_geom("vae_bn_act_fwd", n_img, H, W, C, pool)) return e;
+    VAE_CHECK(p_drop >= 0.0 && p_drop < 1.0, "vae_bn_act_fwd: p_drop=%f out of [0,1)", p_drop);
+    ActGeom g = {n_img, H, W, C, pool};
+    const DropCfg d = make_drop(p_drop, keep_mask, seed, step, stream_id, rank);
+    const long items = (long)n_img * H * W / (pool ? 4 : 1) * (C / 8);
+    hipStream_t s = (hipStream_t)stream;
+    if (pool) hipLaunchKernelGGL(bn_act_fwd_kernel<true>, dim3(elem_grid(items)), dim3(256), 0, s, (const bf16_t*)y, scale, shift, (bf16_t*)out, g, d);
+    else hipLaunchKernelGGL(bn_act_fwd_kernel<false>, dim3(elem_grid(items)), dim3(256), 0, s, (const bf16_t*)y, scale, shift, (bf16_t*)out, g, d);
+    VAE_LAUNCH_CHECK("bn_act_fwd_kernel");
+    return 0;
+}
+
+extern "C" int vae_bn_act_bwd_blocks(int n_img, int H, int W, int C, int pool) {
+    const long items = (long)n_img * H * W / (pool ? 4 : 1) * (C / 8);
+    long b = (items + 255) / 256;
+    if (b < 1) b = 1;
+    if (b > 1024) b = 1024;
+    return (int)b;
+}
+
+extern "C" int vae_bn_act_bwd(const void* gin, const void* y, const float* scale, const float* shift, const float* mean,
+                              const float* rstd, float* partial, float* sums, void* dy, int n_img, int H, int W, int C,
+                              int pool, double p_drop, const void* keep_mask, unsigned long long seed, unsigned step,
+                              unsigned stream_id, unsigned rank, void* stream) {
+    VAE_CHECK(gin && y && scale && shift && mean && rstd && partial && sums && dy, "vae_bn_act_bwd: null pointer");
+    if (int e = check_geom("vae_bn_act_bwd", n_img, H, W, C, pool)) return e;
+    ActGeom g = {n_img, H, W, C, pool};
+    const DropCfg d = make_drop(p_drop, keep_mask, seed, step, stream_id, rank);
+    const int nb = vae_bn_act_bwd_blocks(n_img, H, W, C, pool);
+    const float inv_count = (float)(1.0 / ((double)n_img * H * W));
+    hipStream_t s = (hipStream_t)stream;
+    const bf16_t* gi = (const bf16_t*)gin;
+    const bf16_t* yy = (const bf16_t*)y;
+    if (pool) hipLaunchKernelGGL((bn_act_bwd_kernel<true, 0>), dim3(nb), dim3(256), 0, s, gi, yy, scale, shift, mean, rstd, sums, inv_count, partial, (bf16_t*)dy, g, d);
+    else hipLaunchKernelGGL((bn_act_bwd_kernel<false, 0>), dim3(nb), dim3(256), 0, s, gi, yy, scale, shift, mean, rstd, sums, inv_count, partial, (bf16_t*)dy, g, d);
+    VAE_LAUNCH_CHECK("bn_act_bwd_kernel<0>");
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((2 * C + 63) / 64), dim3(1024), 0, s, partial, nb, 2 * C, sums, 1.0f);
+    VAE_LAUNCH_CHECK("sum_partials_kernel");
+    const int nb2 = elem_grid((long)n_img * H * W / (pool ? 4 : 1) * (C / 8));
+    if (pool) hipLaunchKernelGGL((bn_act_bwd_kernel<true, 1>), dim3(nb2), dim3(256), 0, s, gi, yy, scale, shift, mean, rstd, sums, inv_count, partial, (bf16_t*)dy, g, d);
+    else hipLaunchKernelGGL((bn_act_bwd_kernel<false, 1>), dim3(nb2), dim3(256), 0, s, gi, yy, scale, shift, mean, rstd, sums, inv_count, partial, (bf16_t*)dy, g, d);
+    VAE_LAUNCH_CHECK("bn_act_bwd_kernel<1>");
+    return 0;
+}
+
+extern "C" int vae_head_fwd(const void* y, const float* scale, const float* shift, const float* w, const float* b,
+                            float* recon, int n_img, int H, int W, int Cout, void* stream) {
+    VAE_CHECK(y && scale && shift && w && b && recon, "vae_head_fwd: null pointer");
+    VAE_CHECK(n_img > 0 && H > 0 && W > 0, "vae_head_fwd: bad geometry");
+    VAE_CHECK(Cout >= 1 && Cout <= 4, "vae_head_fwd: out_channels=%d not supported (1..4)", Cout);
+    const long npix = (long)n_img * H * W;
+    const int grid = elem_grid(npix * 8);
+    hipStream_t s = (hipStream_t)stream;
+#define GO(CO) hipLaunchKernelGGL(head_fwd_kernel<CO>, dim3(grid), dim3(256), 0, s, (const bf16_t*)y, scale, shift, w, b, recon, npix, H * W)
+    switch (Cout) { case 1: GO(1); break; case 2: GO(2); break; case 3: GO(3); break; default: GO(4); }
+#undef GO
+    VAE_LAUNCH_CHECK("head_fwd_kernel");
+    return 0;
+}
+
+extern "C" int vae_head_bwd_blocks(int n_img, int H, int W) {
+    long b = ((long)n_img * H * W + 31) / 32;
+    if (b < 1) b = 1;
+    if (b > 1024) b = 1024;
+    return (int)b;
+}
+
+extern "C" int vae_head_bwd(const float* drecon, const float* recon, const void* y, const float* scale,
+                            const float* shift, const float* mean, const float* rstd, const float* w, float* partial,
+                            float* sums, void* dy, int n_img, int H, int W, int Cout, void* stream) {
+    VAE_CHECK(drecon && recon && y && scale && shift && mean && rstd && w && partial && sums && dy, "vae_head_bwd: null pointer");
+    VAE_CHECK(n_img > 0 && H > 0 && W > 0, "vae_head_bwd: bad geometry");
+    VAE_CHECK(Cout >= 1 && Cout <= 4, "vae_head_bwd: out_channels=%d not supported (1..4)", Cout);
+    const long npix = (long)n_img * H * W;
+    const int nb = vae_head_bwd_blocks(n_img, H, W);
+    const int ncols = (3 + Cout) * 64;
+    const float inv_count = (float)(1.0 / (double)npix);
+    hipStream_t s = (hipStream_t)stream;
+    const bf16_t* yy = (const bf16_t*)y;
+#define GO(CO, PASS, NB) hipLaunchKernelGGL((head_bwd_kernel<CO, PASS>), dim3(NB), dim3(256), 0, s, drecon, recon, yy, scale, shift, mean, rstd, w, sums, inv_count, partial, (bf16_t*)dy, npix, H * W)
+    switch (Cout) { case 1: GO(1, 0, nb); break; case 2: GO(2, 0, nb); break; case 3: GO(3, 0, nb); break; default: GO(4, 0, nb); }
+    VAE_LAUNCH_CHECK("head_bwd_kernel<0>");
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((ncols + 63) / 64), dim3(1024), 0, s, partial, nb, ncols, sums, 1.0f);
+    VAE_LAUNCH_CHECK("sum_partials_kernel");
+    const int nb2 = (int)((npix + 31) / 32 > 2048 ? 2048 : (npix + 31) / 32);
+    switch (Cout) { case 1: GO(1, 1, nb2); break; case 2: GO(2, 1, nb2); break; case 3: GO(3, 1, nb2); break; default: GO(4, 1, nb2); }
+#undef GO
+    VAE_LAUNCH_CHECK("head_bwd_kernel<1>");
+    return 0;
+}
+
+extern "C" int vae_tanh_bwd_rows(int rows) { return rows < 64 ? rows : 64; }
+
+extern "C" int vae_tanh_bwd(const void* dx, const void* h, void* dpre, float* colpartial, int rows, int cols,
+                            void* stream) {
+    VAE_CHECK(dx && h && dpre && colpartial && rows > 0 && cols > 0 && cols % 8 == 0, "vae_tanh_bwd: bad arguments (cols must be a multiple of 8)");
+    dim3 grid((cols / 8 + 255) / 256, vae_tanh_bwd_rows(rows));
+    hipLaunchKernelGGL(tanh_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dx, (const bf16_t*)h,
+                       (bf16_t*)dpre, colpartial, rows, cols);
+    VAE_LAUNCH_CHECK("tanh_bwd_kernel");
+    return 0;
+}
+
+extern "C" int vae_nchw_to_nhwc8(const float* x, void* out, int n_img, int C, int H, int W, void* stream) {
+    VAE_CHECK(x && out && n_img > 0 && H > 0 && W > 0, "vae_nchw_to_nhwc8: bad arguments");
+    VAE_CHECK(C >= 1 && C <= 8, "vae_nchw_to_nhwc8: in_channels=%d not supported (1..8)", C);
+    const long npix = (long)n_img * H * W;
+    hipLaunchKernelGGL(nchw_to_nhwc8_kernel, dim3(elem_grid(npix)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)out,
+                       npix, C, H * W);
+    VAE_LAUNCH_CHECK("nchw_to_nhwc8_kernel");
+    return 0;
+}
