@@ -172,6 +172,59 @@ int vae_tanh_bwd(const void* dx, const void* h, void* dpre, float* colpartial, i
                  void* stream);
 /* inputs.to(device) (train.py:325): NCHW f32 image batch -> NHWC bf16 padded to 8 channels */
 int vae_nchw_to_nhwc8(const float* x, void* out, int n_img, int C, int H, int W, void* stream);
+/* dst[base + i0*s0+i1*s1+i2*s2+i3*s3] = src[e] (fp32 permuting copy); dst_bf16[i] = bf16(src[i]) */
+int vae_permute_f32(const float* src, float* dst, const long* dims4, const long* strides4, long base,
+                    void* stream);
+int vae_cast_bf16(const float* src, void* dst_bf16, long n, void* stream);
+
+/* ---- whole model: VAEConv(in_channels, out_channels, latent_dims, p_dropout, image_size),
+ *      vae/models/vae.py:22-122, as one call per direction --------------------------------------
+ * params / grads : ONE flat fp32 buffer each, the 52 parameters in state_dict order with the
+ *                  reference shapes, tensor i at vae_model_param_offset(cfg, i) (16-byte aligned).
+ * bn_stats       : flat fp32 [running_mean(C) | running_var(C)] for the 11 BatchNorms in module
+ *                  order (conv1.net.1, conv1.net.4, ... conv4.net.4, bn3, bn2, bn1).
+ * wpack          : bf16 operand copies of the weights, vae_model_wpack_bytes(cfg) bytes, refreshed
+ *                  by vae_model_pack_weights after every parameter update.
+ * workspace      : vae_model_workspace_bytes(cfg) bytes; holds the activations between forward
+ *                  and backward, so one workspace per in-flight batch. */
+typedef struct vae_model_cfg {
+    int batch, in_channels, out_channels, latent, image_size;
+    int train;               /* 1: model.train() -- batch statistics, dropout, running stats move */
+    double p_dropout;
+    unsigned long long seed; /* Philox key (config seed) */
+    unsigned step, rank;     /* Philox counter words: forward-call index and data-parallel rank */
+} vae_model_cfg;
+
+long vae_model_param_count(const vae_model_cfg* cfg);              /* floats in params / grads */
+long vae_model_param_offset(const vae_model_cfg* cfg, int index);  /* index 0..51 */
+long vae_model_bn_count(const vae_model_cfg* cfg);
+long vae_model_wpack_bytes(const vae_model_cfg* cfg);
+long vae_model_workspace_bytes(const vae_model_cfg* cfg);
+int vae_model_pack_weights(const vae_model_cfg* cfg, const float* params, void* wpack, void* stream);
+/* VAEConv.forward, vae.py:101-105: x [N,C,S,S] f32 -> recon [N,Cout,S,S], mu, logvar [N,L] f32.
+ * eps_in (optional) replaces the Philox draw of torch.randn_like (vae.py:110); keep_masks
+ * (optional) = 4 uint8 NHWC keep-masks replacing the Philox draws of nn.Dropout (vae.py:137). */
+int vae_model_forward(const vae_model_cfg* cfg, const float* params, float* bn_stats, const void* wpack,
+                      void* workspace, const float* x, const float* eps_in,
+                      const void* const* keep_masks, float* recon, float* mu, float* logvar,
+                      void* stream);
+/* VAEConv.encode, vae.py:89-98 and VAEConv.decode, vae.py:114-122 */
+int vae_model_encode(const vae_model_cfg* cfg, const float* params, float* bn_stats, const void* wpack,
+                     void* workspace, const float* x, const void* const* keep_masks, float* mu,
+                     float* logvar, void* stream);
+int vae_model_decode(const vae_model_cfg* cfg, const float* params, float* bn_stats, const void* wpack,
+                     void* workspace, const float* z, float* recon, void* stream);
+/* the per-workgroup KL partial sums the last vae_model_forward left in the workspace */
+int vae_model_kl_partials(const vae_model_cfg* cfg, void* workspace, const float** kl_partial, int* n);
+/* loss.backward(), train.py:332, for the whole module: grads of all 52 parameters from
+ * d_recon (= d loss / d recon), optional external d loss/d mu, d loss/d logvar, and
+ * kl_scale * KL (kl_scale = kl_weight / batch when the KL term is not in dmu_ext/dlv_ext).
+ * stage -1 = everything; 0 = head..fc_mu/fc_logvar, 1 = conv4+conv3, 2 = conv2+conv1 (in that
+ * order) so that gradient all-reduce of finished layers can overlap the rest. */
+int vae_model_backward(const vae_model_cfg* cfg, const float* params, const void* wpack, void* workspace,
+                       const float* d_recon, const float* recon, const float* mu, const float* logvar,
+                       const float* eps_in, const void* const* keep_masks, const float* dmu_ext,
+                       const float* dlv_ext, float kl_scale, float* grads, int stage, void* stream);
 
 #ifdef __cplusplus
 }

@@ -531,3 +531,112 @@ def tensor_digest(t: torch.Tensor, nsample: int = 256):
     stride = max(1, f.numel() // nsample)
     return (np.array([f.norm().item(), f.sum().item()], dtype=np.float64),
             f[::stride][:nsample].float().numpy().copy())
+
+
+# ----------------------------------------------------------------------------
+# bf16-faithful variant of the forward pass.
+# The MI355X path feeds its matrix cores bf16 operands (fp32 accumulate) and keeps
+# activations / activation gradients in bf16 between kernels.  This restatement
+# rounds at exactly those points, forward and backward, so that the HIP path can
+# be checked against it far more tightly (fp32 summation order only) than against
+# the fp32 reference, from which any bf16 pipeline of this depth differs by the
+# accumulated rounding noise (~3 % at the encoder output for random weights).
+# ----------------------------------------------------------------------------
+def _bf(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+class _RoundFwd(torch.autograd.Function):
+    """bf16 rounding in the forward pass, identity in the backward pass."""
+    @staticmethod
+    def forward(ctx, x):
+        return _bf(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _RoundBwd(torch.autograd.Function):
+    """identity in the forward pass, bf16 rounding of the gradient in the backward pass."""
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _bf(g)
+
+
+def _rf(x):
+    return _RoundFwd.apply(x)
+
+
+def _rb(x):
+    return _RoundBwd.apply(x)
+
+
+def _bn_bf16(y, gamma, beta, rm, rv, train, stats_out, prefix):
+    """statistics from the fp32 conv output, normalisation applied to its bf16 copy."""
+    if train:
+        n = y.numel() // y.shape[1]
+        mean = y.mean(dim=(0, 2, 3))
+        var = y.var(dim=(0, 2, 3), unbiased=False)
+        if stats_out is not None:
+            with torch.no_grad():
+                stats_out[f"{prefix}.running_mean"] = (1 - BN_MOMENTUM) * rm + BN_MOMENTUM * mean
+                stats_out[f"{prefix}.running_var"] = (1 - BN_MOMENTUM) * rv + BN_MOMENTUM * var * (n / max(n - 1, 1))
+    else:
+        mean, var = rm, rv
+    scale = gamma * torch.rsqrt(var + BN_EPS)
+    shift = beta - mean * scale
+    ys = _rb(_rf(y))          # stored bf16; its gradient is stored bf16 too
+    return ys * scale[None, :, None, None] + shift[None, :, None, None]
+
+
+def forward_bf16(x, sd, eps, train=True, p_dropout=0.0, masks=None, stats_out=None):
+    """forward() with the MI355X path's bf16 rounding points (see above)."""
+    masks = masks or [None] * 4
+    h = _bf(x)
+    for i in range(1, 5):
+        for j in (0, 3):
+            w = _rf(sd[f"conv{i}.net.{j}.weight"])
+            y = F.conv2d(h, w, sd[f"conv{i}.net.{j}.bias"], padding=1)
+            b = f"conv{i}.net.{j + 1}"
+            a = torch.relu(_bn_bf16(y, sd[f"{b}.weight"], sd[f"{b}.bias"], sd[f"{b}.running_mean"],
+                                    sd[f"{b}.running_var"], train, stats_out, b))
+            if j == 3:
+                a = dropout(a, p_dropout, train, masks[i - 1])
+                if i <= 3:
+                    a = F.max_pool2d(a, 2)
+            h = _rb(_rf(a))
+    flat = torch.flatten(h, start_dim=1)
+    mu = F.linear(flat, _rf(sd["fc_mu.weight"]), sd["fc_mu.bias"])
+    logvar = F.linear(flat, _rf(sd["fc_logvar.weight"]), sd["fc_logvar.bias"])
+    # the head's input gradient is handed over as bf16 [dmu | dlogvar]
+    z = _rf(reparameterize(_rb(mu), _rb(logvar), eps))
+    nflat = sd["fc_up.weight"].shape[0]
+    hw = int(round(math.sqrt(nflat // 256)))
+    pre = _rb(F.linear(z, _rf(sd["fc_up.weight"]), sd["fc_up.bias"]))
+    h = _rb(_rf(torch.tanh(pre))).view(-1, 256, hw, hw)
+    for k, (up, bn) in enumerate((("up3", "bn3"), ("up2", "bn2"), ("up1", "bn1"))):
+        y = F.conv_transpose2d(h, _rf(sd[f"{up}.weight"]), sd[f"{up}.bias"], stride=2)
+        a = torch.relu(_bn_bf16(y, sd[f"{bn}.weight"], sd[f"{bn}.bias"], sd[f"{bn}.running_mean"],
+                                sd[f"{bn}.running_var"], train, stats_out, bn))
+        h = _rb(_rf(a)) if k < 2 else a      # the 1x1 head reads relu(bn1(.)) without storing it
+    recon = torch.sigmoid(F.conv2d(h, sd["head.weight"], sd["head.bias"]))
+    return recon, mu, logvar
+
+
+def loss_and_grads_bf16(x, sd, eps, kind="l1", kl_weight=1.0, p_dropout=0.0, masks=None):
+    """loss_and_grads() through forward_bf16 (train mode)."""
+    params = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items() if is_param(k)}
+    full = dict(sd)
+    full.update(params)
+    stats = {}
+    recon, mu, logvar = forward_bf16(x, full, eps, True, p_dropout, masks, stats)
+    loss = vae_loss(recon, x, mu, logvar, kind, kl_weight)
+    gl = torch.autograd.grad(loss, list(params.values()), allow_unused=True)
+    grads = {k: (g if g is not None else torch.zeros_like(params[k]))
+             for k, g in zip(params.keys(), gl)}
+    return loss.detach(), recon.detach(), mu.detach(), logvar.detach(), grads, stats

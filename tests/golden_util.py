@@ -89,3 +89,22 @@ def zero_grad_bias(name: str) -> bool:
     noise there (~1e-6) and a relative comparison is meaningless -> absolute floor."""
     import re
     return bool(re.fullmatch(r"conv\d\.net\.[03]\.bias|up\d\.bias", name))
+
+
+def digest_rel_err(case, prefix, name, t, nsample=256):
+    """relative L2 error of tensor ``t`` against the stored golden entry: exact over the full
+    tensor when the fixture holds it, otherwise estimated on the strided sample; also returns
+    the reference rms (to apply an absolute floor to analytically-zero tensors)."""
+    z = case.z
+    ref_dig = z[f"{prefix}/{name}/digest"]
+    rms = ref_dig[0] / np.sqrt(max(t.numel(), 1))
+    key = f"{prefix}/{name}/full"
+    if key in z.files:
+        ref = torch.from_numpy(z[key]).reshape(-1).double()
+        got = t.detach().float().cpu().reshape(-1).double()
+    else:
+        _, smp = O.tensor_digest(t.detach().float().cpu(), nsample)
+        ref = torch.from_numpy(z[f"{prefix}/{name}/sample"]).double()
+        got = torch.from_numpy(smp).double()
+    err = (got - ref).norm().item()
+    return err / max(ref.norm().item(), 1e-30), err / np.sqrt(max(ref.numel(), 1)), rms

@@ -52,7 +52,27 @@ SIGNATURES = {
     "vae_tanh_bwd_rows": (c_int, [c_int]),
     "vae_tanh_bwd": (None, [P, P, P, P, c_int, c_int, P]),
     "vae_nchw_to_nhwc8": (None, [P, P, c_int, c_int, c_int, c_int, P]),
+    "vae_permute_f32": (None, [P, P, P, P, c_long, P]),
+    "vae_cast_bf16": (None, [P, P, c_long, P]),
+    "vae_model_param_count": (c_long, [P]),
+    "vae_model_param_offset": (c_long, [P, c_int]),
+    "vae_model_bn_count": (c_long, [P]),
+    "vae_model_wpack_bytes": (c_long, [P]),
+    "vae_model_workspace_bytes": (c_long, [P]),
+    "vae_model_pack_weights": (None, [P, P, P, P]),
+    "vae_model_forward": (None, [P, P, P, P, P, P, P, P, P, P, P, P]),
+    "vae_model_encode": (None, [P, P, P, P, P, P, P, P, P, P]),
+    "vae_model_decode": (None, [P, P, P, P, P, P, P, P]),
+    "vae_model_kl_partials": (None, [P, P, P, P]),
+    "vae_model_backward": (None, [P, P, P, P, P, P, P, P, P, P, P, P, c_float, P, c_int, P]),
 }
+
+
+class ModelCfg(ctypes.Structure):
+    """mirror of struct vae_model_cfg (include/vae_hip.h)."""
+    _fields_ = [("batch", c_int), ("in_channels", c_int), ("out_channels", c_int), ("latent", c_int),
+                ("image_size", c_int), ("train", c_int), ("p_dropout", c_double),
+                ("seed", c_ulonglong), ("step", c_uint), ("rank", c_uint)]
 
 
 def long4(*v):

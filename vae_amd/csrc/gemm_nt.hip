@@ -209,6 +209,17 @@ __global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict_
         dst[map_index(mp, e)] = f2bf(src[e]);
 }
 
+__global__ __launch_bounds__(256) void permute_f32_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                          long n, IndexMap mp) {
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x)
+        dst[map_index(mp, e)] = src[e];
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n) {
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x)
+        dst[e] = f2bf(src[e]);
+}
+
 static int ilog2_exact(int v) {
     if (v <= 0 || (v & (v - 1))) return -1;
     int s = 0;
@@ -313,5 +324,25 @@ extern "C" int vae_pack_bf16(const float* src, void* dst, const long* dims4, con
     const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
     hipLaunchKernelGGL(pack_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n, mp);
     VAE_LAUNCH_CHECK("pack_bf16_kernel");
+    return 0;
+}
+
+extern "C" int vae_permute_f32(const float* src, float* dst, const long* dims4, const long* strides4, long base,
+                               void* stream) {
+    VAE_CHECK(src && dst, "vae_permute_f32: null pointer");
+    IndexMap mp;
+    if (int e = make_map(mp, dims4, strides4, base, "vae_permute_f32")) return e;
+    const long n = dims4[0] * dims4[1] * dims4[2] * dims4[3];
+    const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL(permute_f32_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, dst, n, mp);
+    VAE_LAUNCH_CHECK("permute_f32_kernel");
+    return 0;
+}
+
+extern "C" int vae_cast_bf16(const float* src, void* dst, long n, void* stream) {
+    VAE_CHECK(src && dst && n > 0, "vae_cast_bf16: bad arguments");
+    const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n);
+    VAE_LAUNCH_CHECK("cast_bf16_kernel");
     return 0;
 }

@@ -1,0 +1,548 @@
+// Whole-model entry points: VAEConv.forward / backward as ONE C call each, enqueuing every
+// kernel of the path on the caller's stream (no per-layer host round trips, no allocation).
+// Layer order follows the reference module exactly:
+//   encode  vae/models/vae.py:89-98   (4 x DoubleConv, 3 x MaxPool2d, fc_mu | fc_logvar)
+//   reparameterize                     vae/models/vae.py:108-111
+//   decode  vae/models/vae.py:114-122 (fc_up + tanh, 3 x ConvTranspose2d + BN + ReLU, 1x1 head + sigmoid)
+// Parameters live in ONE flat fp32 buffer in state_dict order (reference shapes), gradients
+// in a second flat buffer of the same layout; BatchNorm running stats in a third.
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include "../../include/vae_hip.h"
+
+namespace vae {
+void set_error(const char* fmt, ...);
+}
+
+#define CHECK(cond, ...)                   \
+    do {                                   \
+        if (!(cond)) {                     \
+            ::vae::set_error(__VA_ARGS__); \
+            return 1;                      \
+        }                                  \
+    } while (0)
+#define TRY(expr)                 \
+    do {                          \
+        int e__ = (expr);         \
+        if (e__) return e__;      \
+    } while (0)
+
+namespace {
+
+const int ENC_C[4] = {64, 128, 256, 256};
+const int DEC_CI[3] = {256, 128, 64};   // up3, up2, up1
+const int DEC_CO[3] = {128, 64, 64};
+
+inline long align_up(long v, long a) { return (v + a - 1) / a * a; }
+
+// ------------------------------------------------------------------ parameter layout
+enum {
+    P_FC_MU_W = 32, P_FC_MU_B, P_FC_LV_W, P_FC_LV_B, P_FC_UP_W, P_FC_UP_B,
+    P_UP3_W, P_UP3_B, P_BN3_G, P_BN3_B, P_UP2_W, P_UP2_B, P_BN2_G, P_BN2_B,
+    P_UP1_W, P_UP1_B, P_BN1_G, P_BN1_B, P_HEAD_W, P_HEAD_B, P_COUNT
+};
+// encoder block b (0..3): conv a weight = 8b, bias 8b+1, gamma 8b+2, beta 8b+3, conv b weight 8b+4, ...
+
+struct Dims {
+    int N, Cin, Cout, L, S, hw, F;   // hw = (S/8)^2, F = 256*hw
+};
+
+struct ParamLayout {
+    long off[P_COUNT], numel[P_COUNT], total;
+    long bn_off[11], bn_total;   // running_mean at bn_off, running_var at bn_off + C
+    int bn_c[11];
+};
+
+int make_dims(const vae_model_cfg* c, Dims* d, const char* who) {
+    CHECK(c, "%s: null config", who);
+    CHECK(c->batch > 0, "%s: batch must be > 0 (got %d)", who, c->batch);
+    CHECK(c->in_channels >= 1 && c->in_channels <= 8, "%s: in_channels=%d not supported (1..8)", who, c->in_channels);
+    CHECK(c->out_channels >= 1 && c->out_channels <= 4, "%s: out_channels=%d not supported (1..4)", who, c->out_channels);
+    CHECK(c->image_size >= 8 && c->image_size % 8 == 0, "%s: image_size=%d must be a positive multiple of 8", who, c->image_size);
+    CHECK(c->latent >= 64 && c->latent % 64 == 0, "%s: latent_dims=%d must be a positive multiple of 64", who, c->latent);
+    CHECK(c->p_dropout >= 0.0 && c->p_dropout < 1.0, "%s: p_dropout=%f out of [0,1)", who, c->p_dropout);
+    CHECK((long)c->batch * c->image_size * c->image_size < (1L << 31), "%s: batch x image_size^2 exceeds 2^31 pixels", who);
+    d->N = c->batch; d->Cin = c->in_channels; d->Cout = c->out_channels; d->L = c->latent; d->S = c->image_size;
+    d->hw = (d->S / 8) * (d->S / 8);
+    d->F = 256 * d->hw;
+    return 0;
+}
+
+void make_param_layout(const Dims& d, ParamLayout* pl) {
+    long o = 0;
+    auto put = [&](int idx, long n) {
+        pl->off[idx] = o;
+        pl->numel[idx] = n;
+        o += align_up(n, 4);
+    };
+    int ci = d.Cin;
+    for (int b = 0; b < 4; ++b) {
+        const int co = ENC_C[b];
+        put(8 * b + 0, (long)co * ci * 9); put(8 * b + 1, co); put(8 * b + 2, co); put(8 * b + 3, co);
+        put(8 * b + 4, (long)co * co * 9); put(8 * b + 5, co); put(8 * b + 6, co); put(8 * b + 7, co);
+        ci = co;
+    }
+    put(P_FC_MU_W, (long)d.L * d.F); put(P_FC_MU_B, d.L);
+    put(P_FC_LV_W, (long)d.L * d.F); put(P_FC_LV_B, d.L);
+    put(P_FC_UP_W, (long)d.F * d.L); put(P_FC_UP_B, d.F);
+    for (int u = 0; u < 3; ++u) {
+        const int base = P_UP3_W + 4 * u;
+        put(base, (long)DEC_CI[u] * DEC_CO[u] * 4); put(base + 1, DEC_CO[u]); put(base + 2, DEC_CO[u]); put(base + 3, DEC_CO[u]);
+    }
+    put(P_HEAD_W, (long)d.Cout * 64); put(P_HEAD_B, d.Cout);
+    pl->total = o;
+    long bo = 0;
+    for (int i = 0; i < 11; ++i) {
+        const int C = i < 8 ? ENC_C[i / 2] : DEC_CO[i - 8];
+        pl->bn_c[i] = C;
+        pl->bn_off[i] = bo;
+        bo += 2 * C;
+    }
+    pl->bn_total = bo;
+}
+
+// ------------------------------------------------------------------ packed-weight layout (bf16 unless noted)
+struct PackLayout {
+    long c1a;               // [64][16][8]
+    long conv_f[7], conv_d[7];   // c1b, c2a, c2b, c3a, c3b, c4a, c4b
+    long fc_f, fc_d, up_f, up_d; // fc_mu|fc_logvar and fc_up
+    long ct_f[3], ct_d[3];
+    long bcat, bup;         // fp32: [2L], [F] in NHWC order
+    long total_bytes;
+};
+const int CONV_CI[7] = {64, 64, 128, 128, 256, 256, 256};
+const int CONV_CO[7] = {64, 128, 128, 256, 256, 256, 256};
+const int CONV_PARAM[7] = {4, 8, 12, 16, 20, 24, 28};   // weight index in the param table
+
+void make_pack_layout(const Dims& d, PackLayout* k) {
+    long o = 0;
+    auto put = [&](long bytes) { long r = o; o += align_up(bytes, 256); return r; };
+    k->c1a = put(64 * 128 * 2);
+    for (int i = 0; i < 7; ++i) {
+        k->conv_f[i] = put((long)CONV_CO[i] * 9 * CONV_CI[i] * 2);
+        k->conv_d[i] = put((long)CONV_CO[i] * 9 * CONV_CI[i] * 2);
+    }
+    k->fc_f = put(2L * d.L * d.F * 2); k->fc_d = put(2L * d.L * d.F * 2);
+    k->up_f = put((long)d.L * d.F * 2); k->up_d = put((long)d.L * d.F * 2);
+    for (int u = 0; u < 3; ++u) {
+        k->ct_f[u] = put((long)DEC_CI[u] * DEC_CO[u] * 4 * 2);
+        k->ct_d[u] = put((long)DEC_CI[u] * DEC_CO[u] * 4 * 2);
+    }
+    k->bcat = put(2L * d.L * 4);
+    k->bup = put((long)d.F * 4);
+    k->total_bytes = o;
+}
+
+// ------------------------------------------------------------------ workspace layout
+struct WsLayout {
+    long x8;
+    long ya[4], aa[4], yb[4], ob[4];
+    long coef;              // 11 x 4 x 256 floats: scale, shift, mean, rstd
+    long stat_sum, stat_sq; // GEMM epilogue partials
+    long zb, klp, h, yd[3], ad[2];
+    long g0, g1, bnpart, headpart, headsums, slab, dz, dmu, dlv, dcat, dpre, colp;
+    long slab_floats;
+    long total_bytes;
+};
+
+long enc_elems(const Dims& d, int b) { const long h = d.S >> b; return (long)d.N * h * h * ENC_C[b]; }
+
+int rows_blocks(long M) { return (int)((M + vae_gemm_rows_per_block() - 1) / vae_gemm_rows_per_block()); }
+
+long slab_need(int M, int N, int taps, long K) { return (long)vae_wgrad_ksplit(M, N, taps, K) * taps * M * N; }
+
+void make_ws_layout(const Dims& d, WsLayout* w) {
+    long o = 0;
+    auto put = [&](long bytes) { long r = o; o += align_up(bytes, 256); return r; };
+    const long npix = (long)d.N * d.S * d.S;
+    w->x8 = put(npix * 8 * 2);
+    for (int b = 0; b < 4; ++b) {
+        const long e = enc_elems(d, b);
+        w->ya[b] = put(e * 2); w->aa[b] = put(e * 2); w->yb[b] = put(e * 2);
+        w->ob[b] = put((b < 3 ? e / 4 : e) * 2);
+    }
+    w->coef = put(11L * 4 * 256 * 4);
+    const long stat = (long)rows_blocks(npix) * 64;       // widest: first block (64 ch at full res) == up1 (256 cols at half res)
+    const long stat2 = (long)rows_blocks(npix / 4) * 256;
+    const long statn = stat > stat2 ? stat : stat2;
+    w->stat_sum = put(statn * 4); w->stat_sq = put(statn * 4);
+    w->zb = put((long)d.N * d.L * 2);
+    w->klp = put(2048 * 4);
+    w->h = put((long)d.N * d.F * 2);
+    const int s8 = d.S / 8;
+    for (int u = 0; u < 3; ++u) {
+        const long hh = (long)s8 << (u + 1);
+        w->yd[u] = put((long)d.N * hh * hh * DEC_CO[u] * 2);
+        if (u < 2) w->ad[u] = put((long)d.N * hh * hh * DEC_CO[u] * 2);
+    }
+    w->g0 = put(npix * 64 * 2); w->g1 = put(npix * 64 * 2);
+    w->bnpart = put(1024L * 512 * 4);
+    w->headpart = put(1024L * 7 * 64 * 4);
+    w->headsums = put(7 * 64 * 4);
+    long s = slab_need(64, 64, 2, npix);
+    for (int i = 0; i < 7; ++i) {
+        const int b = (i + 1) / 2;     // encoder block of conv i (c1b -> 0, c2a,c2b -> 1, ...)
+        const long h = d.S >> b;
+        const long v = slab_need(CONV_CO[i], CONV_CI[i], 9, (long)d.N * h * h);
+        if (v > s) s = v;
+    }
+    for (int u = 0; u < 3; ++u) {
+        const long hh = (long)s8 << u;
+        const long v = slab_need(DEC_CO[u], DEC_CI[u], 4, (long)d.N * hh * hh);
+        if (v > s) s = v;
+    }
+    { const long v = slab_need(2 * d.L, d.F, 1, d.N); if (v > s) s = v; }
+    { const long v = slab_need(d.F, d.L, 1, d.N); if (v > s) s = v; }
+    w->slab_floats = s;
+    w->slab = put(s * 4);
+    w->dz = put((long)d.N * d.L * 4); w->dmu = put((long)d.N * d.L * 4); w->dlv = put((long)d.N * d.L * 4);
+    w->dcat = put((long)d.N * 2 * d.L * 2);
+    w->dpre = put((long)d.N * d.F * 2);
+    w->colp = put(64L * d.F * 4);
+    w->total_bytes = o;
+}
+
+struct Ctx {
+    Dims d;
+    ParamLayout pl;
+    PackLayout pk;
+    WsLayout ws;
+    const vae_model_cfg* cfg;
+    float* params;
+    float* grads;
+    float* bn;
+    char* wpack;
+    char* w;
+    void* stream;
+    float* P(int i) const { return params + pl.off[i]; }
+    float* G(int i) const { return grads + pl.off[i]; }
+    float* coef(int bn_idx, int which) const { return (float*)(w + ws.coef) + ((long)bn_idx * 4 + which) * 256; }
+    void* at(long off) const { return w + off; }
+    void* pk_at(long off) const { return wpack + off; }
+};
+
+int make_ctx(Ctx* c, const vae_model_cfg* cfg, const char* who) {
+    TRY(make_dims(cfg, &c->d, who));
+    make_param_layout(c->d, &c->pl);
+    make_pack_layout(c->d, &c->pk);
+    make_ws_layout(c->d, &c->ws);
+    c->cfg = cfg;
+    return 0;
+}
+
+int pack4(const float* src, void* dst, long d0, long d1, long d2, long d3, long s0, long s1, long s2, long s3, long base,
+          void* stream) {
+    const long dims[4] = {d0, d1, d2, d3}, st[4] = {s0, s1, s2, s3};
+    return vae_pack_bf16(src, dst, dims, st, base, stream);
+}
+int perm4(const float* src, float* dst, long d0, long d1, long d2, long d3, long s0, long s1, long s2, long s3, long base,
+          void* stream) {
+    const long dims[4] = {d0, d1, d2, d3}, st[4] = {s0, s1, s2, s3};
+    return vae_permute_f32(src, dst, dims, st, base, stream);
+}
+int reduce4(const float* slab, int ns, long stride, float* out, long d0, long d1, long d2, long d3, long s0, long s1,
+            long s2, long s3, long base, void* stream) {
+    const long dims[4] = {d0, d1, d2, d3}, st[4] = {s0, s1, s2, s3};
+    return vae_reduce_slabs(slab, ns, stride, out, dims, st, base, 0, stream);
+}
+
+// BatchNorm finalize for BN `bi` from the GEMM epilogue partials (train) or running stats (eval)
+int bn_finalize(const Ctx& c, int bi, int g_idx, int rows, int fold, double count) {
+    const int C = c.pl.bn_c[bi];
+    float* rm = c.bn + c.pl.bn_off[bi];
+    const int train = c.cfg->train;
+    return vae_bn_finalize((const float*)c.at(c.ws.stat_sum), (const float*)c.at(c.ws.stat_sq), rows, C, fold, count,
+                           c.P(g_idx), c.P(g_idx + 1), rm, rm + C, 0.1f, 1e-5f, train ? 0 : 1, c.coef(bi, 0),
+                           c.coef(bi, 1), c.coef(bi, 2), c.coef(bi, 3), c.stream);
+}
+
+}  // namespace
+
+// ==================================================================== public API
+extern "C" long vae_model_param_count(const vae_model_cfg* cfg) {
+    Ctx c;
+    if (make_ctx(&c, cfg, "vae_model_param_count")) return -1;
+    return c.pl.total;
+}
+extern "C" long vae_model_param_offset(const vae_model_cfg* cfg, int index) {
+    Ctx c;
+    if (make_ctx(&c, cfg, "vae_model_param_offset")) return -1;
+    if (index < 0 || index >= P_COUNT) return -1;
+    return c.pl.off[index];
+}
+extern "C" long vae_model_bn_count(const vae_model_cfg* cfg) {
+    Ctx c;
+    if (make_ctx(&c, cfg, "vae_model_bn_count")) return -1;
+    return c.pl.bn_total;
+}
+extern "C" long vae_model_wpack_bytes(const vae_model_cfg* cfg) {
+    Ctx c;
+    if (make_ctx(&c, cfg, "vae_model_wpack_bytes")) return -1;
+    return c.pk.total_bytes;
+}
+extern "C" long vae_model_workspace_bytes(const vae_model_cfg* cfg) {
+    Ctx c;
+    if (make_ctx(&c, cfg, "vae_model_workspace_bytes")) return -1;
+    return c.ws.total_bytes;
+}
+
+extern "C" int vae_model_pack_weights(const vae_model_cfg* cfg, const float* params, void* wpack, void* stream) {
+    Ctx c;
+    TRY(make_ctx(&c, cfg, "vae_model_pack_weights"));
+    CHECK(params && wpack, "vae_model_pack_weights: null pointer");
+    c.params = (float*)params; c.wpack = (char*)wpack; c.stream = stream;
+    const Dims& d = c.d;
+    hipStream_t s = (hipStream_t)stream;
+    CHECK(hipMemsetAsync(c.pk_at(c.pk.c1a), 0, 64 * 128 * 2, s) == hipSuccess, "vae_model_pack_weights: memset failed");
+    TRY(pack4(c.P(0), c.pk_at(c.pk.c1a), 64, d.Cin, 9, 1, 128, 1, 8, 0, 0, stream));
+    for (int i = 0; i < 7; ++i) {
+        const long Ci = CONV_CI[i], Co = CONV_CO[i];
+        TRY(pack4(c.P(CONV_PARAM[i]), c.pk_at(c.pk.conv_f[i]), Co, Ci, 9, 1, 9 * Ci, 1, Ci, 0, 0, stream));
+        TRY(pack4(c.P(CONV_PARAM[i]), c.pk_at(c.pk.conv_d[i]), Co, Ci, 9, 1, 1, 9 * Co, -Co, 0, 8 * Co, stream));
+    }
+    const long L = d.L, F = d.F, hw = d.hw;
+    for (int t = 0; t < 2; ++t) {   // fc_mu, fc_logvar -> one [2L][F] operand, columns in NHWC order
+        const float* src = c.P(t ? P_FC_LV_W : P_FC_MU_W);
+        TRY(pack4(src, c.pk_at(c.pk.fc_f), L, 256, hw, 1, F, 1, 256, 0, t * L * F, stream));
+        TRY(pack4(src, c.pk_at(c.pk.fc_d), L, 256, hw, 1, 1, 2 * L, 256 * 2 * L, 0, t * L, stream));
+        TRY(perm4(c.P(t ? P_FC_LV_B : P_FC_MU_B), (float*)c.pk_at(c.pk.bcat), L, 1, 1, 1, 1, 0, 0, 0, t * L, stream));
+    }
+    TRY(pack4(c.P(P_FC_UP_W), c.pk_at(c.pk.up_f), 256, hw, L, 1, L, 256 * L, 1, 0, 0, stream));
+    TRY(pack4(c.P(P_FC_UP_W), c.pk_at(c.pk.up_d), 256, hw, L, 1, 1, 256, F, 0, 0, stream));
+    TRY(perm4(c.P(P_FC_UP_B), (float*)c.pk_at(c.pk.bup), 256, hw, 1, 1, 1, 256, 0, 0, 0, stream));
+    for (int u = 0; u < 3; ++u) {
+        const long Ci = DEC_CI[u], Co = DEC_CO[u];
+        const float* src = c.P(P_UP3_W + 4 * u);
+        TRY(pack4(src, c.pk_at(c.pk.ct_f[u]), Ci, Co, 4, 1, 1, Ci, Co * Ci, 0, 0, stream));
+        TRY(pack4(src, c.pk_at(c.pk.ct_d[u]), Ci, Co, 4, 1, 4 * Co, 1, Co, 0, 0, stream));
+    }
+    return 0;
+}
+
+// Decoder forward from z (bf16 [N][L] in the workspace) to recon; shared by forward and decode.
+static int decoder_forward(const Ctx& c, float* recon) {
+    const Dims& d = c.d;
+    const WsLayout& w = c.ws;
+    const int s8 = d.S / 8;
+    const int train = c.cfg->train;
+    TRY(vae_linear_gemm(c.at(w.zb), c.pk_at(c.pk.up_f), (const float*)c.pk_at(c.pk.bup), c.at(w.h), nullptr, nullptr,
+                        nullptr, d.N, d.F, d.L, VAE_EPI_TANH_BF16, c.stream));
+    const void* in = c.at(w.h);
+    for (int u = 0; u < 3; ++u) {
+        const int hh = s8 << u;   // input grid of this ConvTranspose
+        const long Min = (long)d.N * hh * hh;
+        float* ss = train ? (float*)c.at(w.stat_sum) : nullptr;
+        float* sq = train ? (float*)c.at(w.stat_sq) : nullptr;
+        TRY(vae_convt2x2_fwd_gemm(in, c.pk_at(c.pk.ct_f[u]), c.P(P_UP3_B + 4 * u), c.at(w.yd[u]), ss, sq, d.N, hh, hh,
+                                  DEC_CI[u], DEC_CO[u], c.stream));
+        TRY(bn_finalize(c, 8 + u, P_BN3_G + 4 * u, rows_blocks(Min), 4, 4.0 * (double)Min));
+        if (u < 2) {
+            TRY(vae_bn_act_fwd(c.at(w.yd[u]), c.coef(8 + u, 0), c.coef(8 + u, 1), c.at(w.ad[u]), d.N, 2 * hh, 2 * hh,
+                               DEC_CO[u], 0, 0.0, nullptr, 0, 0, 0, 0, c.stream));
+            in = c.at(w.ad[u]);
+        }
+    }
+    return vae_head_fwd(c.at(w.yd[2]), c.coef(10, 0), c.coef(10, 1), c.P(P_HEAD_W), c.P(P_HEAD_B), recon, d.N, d.S, d.S,
+                        d.Cout, c.stream);
+}
+
+static int encoder_forward(const Ctx& c, const float* x, const void* const* masks, float* mu, float* logvar) {
+    const Dims& d = c.d;
+    const WsLayout& w = c.ws;
+    const int train = c.cfg->train;
+    const double p = train ? c.cfg->p_dropout : 0.0;
+    float* ss = train ? (float*)c.at(w.stat_sum) : nullptr;
+    float* sq = train ? (float*)c.at(w.stat_sq) : nullptr;
+    TRY(vae_nchw_to_nhwc8(x, c.at(w.x8), d.N, d.Cin, d.S, d.S, c.stream));
+    const void* in = c.at(w.x8);
+    for (int b = 0; b < 4; ++b) {
+        const int H = d.S >> b, C = ENC_C[b];
+        const long M = (long)d.N * H * H;
+        const int rows = rows_blocks(M);
+        if (b == 0)
+            TRY(vae_conv3x3_c8_gemm(in, c.pk_at(c.pk.c1a), c.P(1), c.at(w.ya[0]), ss, sq, d.N, H, H, C, c.stream));
+        else
+            TRY(vae_conv3x3_gemm(in, c.pk_at(c.pk.conv_f[2 * b - 1]), c.P(8 * b + 1), c.at(w.ya[b]), ss, sq, d.N, H, H,
+                                 ENC_C[b - 1], C, c.stream));
+        TRY(bn_finalize(c, 2 * b, 8 * b + 2, rows, 1, (double)M));
+        TRY(vae_bn_act_fwd(c.at(w.ya[b]), c.coef(2 * b, 0), c.coef(2 * b, 1), c.at(w.aa[b]), d.N, H, H, C, 0, 0.0, nullptr,
+                           0, 0, 0, 0, c.stream));
+        TRY(vae_conv3x3_gemm(c.at(w.aa[b]), c.pk_at(c.pk.conv_f[2 * b]), c.P(8 * b + 5), c.at(w.yb[b]), ss, sq, d.N, H, H, C,
+                             C, c.stream));
+        TRY(bn_finalize(c, 2 * b + 1, 8 * b + 6, rows, 1, (double)M));
+        TRY(vae_bn_act_fwd(c.at(w.yb[b]), c.coef(2 * b + 1, 0), c.coef(2 * b + 1, 1), c.at(w.ob[b]), d.N, H, H, C, b < 3, p,
+                           masks ? masks[b] : nullptr, c.cfg->seed, c.cfg->step, VAE_STREAM_DROPOUT0 + b, c.cfg->rank,
+                           c.stream));
+        in = c.at(w.ob[b]);
+    }
+    return vae_linear_gemm(in, c.pk_at(c.pk.fc_f), (const float*)c.pk_at(c.pk.bcat), mu, logvar, nullptr, nullptr, d.N,
+                           2 * d.L, d.F, VAE_EPI_F32_SPLIT, c.stream);
+}
+
+extern "C" int vae_model_forward(const vae_model_cfg* cfg, const float* params, float* bn_stats, const void* wpack,
+                                 void* workspace, const float* x, const float* eps_in, const void* const* keep_masks,
+                                 float* recon, float* mu, float* logvar, void* stream) {
+    Ctx c;
+    TRY(make_ctx(&c, cfg, "vae_model_forward"));
+    CHECK(params && bn_stats && wpack && workspace && x && recon && mu && logvar, "vae_model_forward: null pointer");
+    c.params = (float*)params; c.bn = bn_stats; c.wpack = (char*)wpack; c.w = (char*)workspace; c.stream = stream;
+    TRY(encoder_forward(c, x, keep_masks, mu, logvar));
+    TRY(vae_reparam_kl_fwd(mu, logvar, eps_in, nullptr, c.at(c.ws.zb), nullptr, (float*)c.at(c.ws.klp),
+                           (long)c.d.N * c.d.L, cfg->seed, cfg->step, cfg->rank, stream));
+    return decoder_forward(c, recon);
+}
+
+extern "C" int vae_model_encode(const vae_model_cfg* cfg, const float* params, float* bn_stats, const void* wpack,
+                                void* workspace, const float* x, const void* const* keep_masks, float* mu,
+                                float* logvar, void* stream) {
+    Ctx c;
+    TRY(make_ctx(&c, cfg, "vae_model_encode"));
+    CHECK(params && bn_stats && wpack && workspace && x && mu && logvar, "vae_model_encode: null pointer");
+    c.params = (float*)params; c.bn = bn_stats; c.wpack = (char*)wpack; c.w = (char*)workspace; c.stream = stream;
+    return encoder_forward(c, x, keep_masks, mu, logvar);
+}
+
+extern "C" int vae_model_decode(const vae_model_cfg* cfg, const float* params, float* bn_stats, const void* wpack,
+                                void* workspace, const float* z, float* recon, void* stream) {
+    Ctx c;
+    TRY(make_ctx(&c, cfg, "vae_model_decode"));
+    CHECK(params && bn_stats && wpack && workspace && z && recon, "vae_model_decode: null pointer");
+    c.params = (float*)params; c.bn = bn_stats; c.wpack = (char*)wpack; c.w = (char*)workspace; c.stream = stream;
+    TRY(vae_cast_bf16(z, c.at(c.ws.zb), (long)c.d.N * c.d.L, stream));
+    return decoder_forward(c, recon);
+}
+
+extern "C" int vae_model_kl_partials(const vae_model_cfg* cfg, void* workspace, const float** kl_partial, int* n) {
+    Ctx c;
+    TRY(make_ctx(&c, cfg, "vae_model_kl_partials"));
+    CHECK(workspace && kl_partial && n, "vae_model_kl_partials: null pointer");
+    *kl_partial = (const float*)((char*)workspace + c.ws.klp);
+    *n = vae_reparam_grid((long)c.d.N * c.d.L);
+    return 0;
+}
+
+// ------------------------------------------------------------------ backward
+static int wgrad_to(const Ctx& c, const void* P, const void* Q, int M, int N, long K, int ldp, int ldq, int mode, int H,
+                    int W, int taps, int* nsplit_out) {
+    const int ns = vae_wgrad_ksplit(M, N, taps, K);
+    *nsplit_out = ns;
+    return vae_wgrad_gemm(P, Q, (float*)c.at(c.ws.slab), M, N, K, ldp, ldq, mode, H, W, ns, c.stream);
+}
+
+static int zero_grad(const Ctx& c, int idx) {
+    CHECK(hipMemsetAsync(c.G(idx), 0, c.pl.numel[idx] * 4, (hipStream_t)c.stream) == hipSuccess, "memset failed");
+    return 0;
+}
+
+// stage 0: head .. fc heads (everything after the encoder); leaves d(encoder output) in g-buffer `cur`
+static int backward_decoder(const Ctx& c, const float* d_recon, const float* recon, const float* mu, const float* logvar,
+                            const float* eps_in, const float* dmu_ext, const float* dlv_ext, float kl_scale) {
+    const Dims& d = c.d;
+    const WsLayout& w = c.ws;
+    const int s8 = d.S / 8;
+    hipStream_t s = (hipStream_t)c.stream;
+    int ns = 1;
+    // 1x1 head + bn1
+    float* hs = (float*)c.at(w.headsums);
+    TRY(vae_head_bwd(d_recon, recon, c.at(w.yd[2]), c.coef(10, 0), c.coef(10, 1), c.coef(10, 2), c.coef(10, 3),
+                     c.P(P_HEAD_W), (float*)c.at(w.headpart), hs, c.at(w.g0), d.N, d.S, d.S, d.Cout, c.stream));
+    CHECK(hipMemcpyAsync(c.G(P_BN1_G), hs, 64 * 4, hipMemcpyDeviceToDevice, s) == hipSuccess &&
+              hipMemcpyAsync(c.G(P_BN1_B), hs + 64, 64 * 4, hipMemcpyDeviceToDevice, s) == hipSuccess &&
+              hipMemcpyAsync(c.G(P_HEAD_W), hs + 128, (long)d.Cout * 64 * 4, hipMemcpyDeviceToDevice, s) == hipSuccess &&
+              hipMemcpyAsync(c.G(P_HEAD_B), hs + 128 + d.Cout * 64, d.Cout * 4, hipMemcpyDeviceToDevice, s) == hipSuccess,
+          "vae_model_backward: gradient copy failed");
+    // up1, up2, up3 (u = 2, 1, 0): dy in g0 -> input grad in g1 -> bn backward -> g0 ...
+    for (int u = 2; u >= 0; --u) {
+        const int hh = s8 << u;    // input grid
+        const long Min = (long)d.N * hh * hh;
+        const int Ci = DEC_CI[u], Co = DEC_CO[u];
+        const void* xin = u == 0 ? c.at(w.h) : c.at(w.ad[u - 1]);
+        TRY(wgrad_to(c, c.at(w.g0), xin, Co, Ci, Min, Co, Ci, VAE_WGRAD_CONVT, hh, hh, 4, &ns));
+        TRY(reduce4((float*)c.at(w.slab), ns, 4L * Co * Ci, c.G(P_UP3_W + 4 * u), Ci, Co, 4, 1, 1, 4 * Ci, Ci, 0, 0, c.stream));
+        TRY(zero_grad(c, P_UP3_B + 4 * u));   // bias in front of a train-mode BatchNorm: gradient is exactly 0
+        TRY(vae_convt2x2_dgrad_gemm(c.at(w.g0), c.pk_at(c.pk.ct_d[u]), c.at(w.g1), d.N, hh, hh, Ci, Co, c.stream));
+        if (u > 0) {
+            const int bi = 8 + (u - 1);
+            TRY(vae_bn_act_bwd(c.at(w.g1), c.at(w.yd[u - 1]), c.coef(bi, 0), c.coef(bi, 1), c.coef(bi, 2), c.coef(bi, 3),
+                               (float*)c.at(w.bnpart), c.G(P_BN3_G + 4 * (u - 1)), c.at(w.g0), d.N, hh, hh, DEC_CO[u - 1], 0,
+                               0.0, nullptr, 0, 0, 0, 0, c.stream));
+        }
+    }
+    // g1 = d h (grad of tanh output) [N][F]
+    const int nr = vae_tanh_bwd_rows(d.N);
+    TRY(vae_tanh_bwd(c.at(w.g1), c.at(w.h), c.at(w.dpre), (float*)c.at(w.colp), d.N, d.F, c.stream));
+    // fc_up.bias grad: column sums, NHWC order -> parameter order via a permuting reduce
+    TRY(reduce4((float*)c.at(w.colp), nr, d.F, c.G(P_FC_UP_B), 256, d.hw, 1, 1, 1, 256, 0, 0, 0, c.stream));
+    TRY(wgrad_to(c, c.at(w.dpre), c.at(w.zb), d.F, d.L, d.N, d.F, d.L, VAE_WGRAD_PLAIN, 1, 1, 1, &ns));
+    TRY(reduce4((float*)c.at(w.slab), ns, (long)d.F * d.L, c.G(P_FC_UP_W), 256, d.hw, d.L, 1, d.L, 256L * d.L, 1, 0, 0, c.stream));
+    TRY(vae_linear_gemm(c.at(w.dpre), c.pk_at(c.pk.up_d), nullptr, c.at(w.dz), nullptr, nullptr, nullptr, d.N, d.L, d.F,
+                        VAE_EPI_F32, c.stream));
+    TRY(vae_reparam_kl_bwd((const float*)c.at(w.dz), mu, logvar, eps_in, dmu_ext, dlv_ext, kl_scale, (float*)c.at(w.dmu),
+                           (float*)c.at(w.dlv), c.at(w.dcat), (long)d.N * d.L, d.L, c.cfg->seed, c.cfg->step, c.cfg->rank,
+                           c.stream));
+    TRY(vae_sum_partials((const float*)c.at(w.dmu), d.N, d.L, c.G(P_FC_MU_B), 1.0f, c.stream));
+    TRY(vae_sum_partials((const float*)c.at(w.dlv), d.N, d.L, c.G(P_FC_LV_B), 1.0f, c.stream));
+    TRY(wgrad_to(c, c.at(w.dcat), c.at(w.ob[3]), 2 * d.L, d.F, d.N, 2 * d.L, d.F, VAE_WGRAD_PLAIN, 1, 1, 1, &ns));
+    for (int t = 0; t < 2; ++t)
+        TRY(reduce4((float*)c.at(w.slab), ns, 2L * d.L * d.F, c.G(t ? P_FC_LV_W : P_FC_MU_W), d.L, 256, d.hw, 1, d.F, 1, 256, 0,
+                    (long)t * d.L * d.F, c.stream));
+    // d(encoder output) [N][F] bf16 -> g0
+    return vae_linear_gemm(c.at(w.dcat), c.pk_at(c.pk.fc_d), nullptr, c.at(w.g0), nullptr, nullptr, nullptr, d.N, d.F,
+                           2 * d.L, VAE_EPI_BF16, c.stream);
+}
+
+// encoder block b: expects d(block output) in g0, leaves d(block input) in g0 (b > 0)
+static int backward_block(const Ctx& c, int b, const void* const* masks) {
+    const Dims& d = c.d;
+    const WsLayout& w = c.ws;
+    const int H = d.S >> b, C = ENC_C[b];
+    const long M = (long)d.N * H * H;
+    int ns = 1;
+    const double p = c.cfg->p_dropout;
+    // second conv + BN + ReLU + dropout (+ pool)
+    TRY(vae_bn_act_bwd(c.at(w.g0), c.at(w.yb[b]), c.coef(2 * b + 1, 0), c.coef(2 * b + 1, 1), c.coef(2 * b + 1, 2),
+                       c.coef(2 * b + 1, 3), (float*)c.at(w.bnpart), c.G(8 * b + 6), c.at(w.g1), d.N, H, H, C, b < 3, p,
+                       masks ? masks[b] : nullptr, c.cfg->seed, c.cfg->step, VAE_STREAM_DROPOUT0 + b, c.cfg->rank, c.stream));
+    TRY(wgrad_to(c, c.at(w.g1), c.at(w.aa[b]), C, C, M, C, C, VAE_WGRAD_CONV3, H, H, 9, &ns));
+    TRY(reduce4((float*)c.at(w.slab), ns, 9L * C * C, c.G(8 * b + 4), C, C, 9, 1, 9 * C, 1, C, 0, 0, c.stream));
+    TRY(zero_grad(c, 8 * b + 5));
+    TRY(vae_conv3x3_gemm(c.at(w.g1), c.pk_at(c.pk.conv_d[2 * b]), nullptr, c.at(w.g0), nullptr, nullptr, d.N, H, H, C, C,
+                         c.stream));
+    // first conv + BN + ReLU
+    TRY(vae_bn_act_bwd(c.at(w.g0), c.at(w.ya[b]), c.coef(2 * b, 0), c.coef(2 * b, 1), c.coef(2 * b, 2), c.coef(2 * b, 3),
+                       (float*)c.at(w.bnpart), c.G(8 * b + 2), c.at(w.g1), d.N, H, H, C, 0, 0.0, nullptr, 0, 0, 0, 0, c.stream));
+    TRY(zero_grad(c, 8 * b + 1));
+    if (b == 0) {
+        TRY(wgrad_to(c, c.at(w.g1), c.at(w.x8), C, 64, M, C, 8, VAE_WGRAD_CONV3_C8, H, H, 2, &ns));
+        return reduce4((float*)c.at(w.slab), ns, 64L * 128, c.G(0), 64, d.Cin, 9, 1, 128, 1, 8, 0, 0, c.stream);
+    }
+    const int Ci = ENC_C[b - 1];
+    TRY(wgrad_to(c, c.at(w.g1), c.at(w.ob[b - 1]), C, Ci, M, C, Ci, VAE_WGRAD_CONV3, H, H, 9, &ns));
+    TRY(reduce4((float*)c.at(w.slab), ns, 9L * C * Ci, c.G(8 * b), C, Ci, 9, 1, 9 * Ci, 1, Ci, 0, 0, c.stream));
+    return vae_conv3x3_gemm(c.at(w.g1), c.pk_at(c.pk.conv_d[2 * b - 1]), nullptr, c.at(w.g0), nullptr, nullptr, d.N, H, H, C,
+                            Ci, c.stream);
+}
+
+extern "C" int vae_model_backward(const vae_model_cfg* cfg, const float* params, const void* wpack, void* workspace,
+                                  const float* d_recon, const float* recon, const float* mu, const float* logvar,
+                                  const float* eps_in, const void* const* keep_masks, const float* dmu_ext,
+                                  const float* dlv_ext, float kl_scale, float* grads, int stage, void* stream) {
+    Ctx c;
+    TRY(make_ctx(&c, cfg, "vae_model_backward"));
+    CHECK(params && wpack && workspace && d_recon && recon && mu && logvar && grads, "vae_model_backward: null pointer");
+    CHECK(cfg->train, "vae_model_backward: the forward pass must have run in train mode");
+    CHECK(stage >= -1 && stage <= 2, "vae_model_backward: stage=%d out of range (-1 all, 0 decoder+latent, 1 conv4+conv3, 2 conv2+conv1)", stage);
+    c.params = (float*)params; c.grads = grads; c.wpack = (char*)wpack; c.w = (char*)workspace; c.stream = stream;
+    if (stage == -1 || stage == 0)
+        TRY(backward_decoder(c, d_recon, recon, mu, logvar, eps_in, dmu_ext, dlv_ext, kl_scale));
+    if (stage == -1 || stage == 1) {
+        TRY(backward_block(c, 3, keep_masks));
+        TRY(backward_block(c, 2, keep_masks));
+    }
+    if (stage == -1 || stage == 2) {
+        TRY(backward_block(c, 1, keep_masks));
+        TRY(backward_block(c, 0, keep_masks));
+    }
+    return 0;
+}

@@ -1,0 +1,207 @@
+"""MI355X drop-in for the loss and train-step entry points of the reference's training
+script (vae/training/train.py:44-55 loss, :324-340 train loop body, :346-355 val body,
+:443-453 config loading).  Same function names and argument order; the arithmetic runs in
+libvae_hip.so (fused reconstruction-loss forward+backward, KL fused with the
+reparameterisation kernels).  The LPIPS perceptual term of the reference (train.py:49) needs
+a pretrained VGG and is not part of this path: percep_weight must be 0 / lpips_fn None.
+"""
+from __future__ import annotations
+
+import os
+import re
+from typing import Callable, Optional
+
+import torch
+import torch.nn.functional as F
+import yaml
+
+from . import _lib
+
+RECON_KINDS = {"l1": 0, "mse": 1, "bce": 2, "bce_logits": 3}
+_CALLABLE_KINDS = {F.l1_loss: 0, F.mse_loss: 1, F.binary_cross_entropy: 2, F.binary_cross_entropy_with_logits: 3}
+
+
+# ---------------------------------------------------------------------- config (train.py:443-453)
+class Config(dict):
+    """dict with attribute access (the subset of OmegaConf's DictConfig the reference uses:
+    config.key reads/writes and ${key} interpolation inside strings)."""
+
+    def __getattr__(self, k):
+        try:
+            v = self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+        if isinstance(v, str) and "${" in v:
+            v = re.sub(r"\$\{([^}]+)\}", lambda m: str(self[m.group(1)]), v)
+        return v
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def _fix_scalars(d):
+    # PyYAML reads "1e-4" (no dot) as a string; OmegaConf reads it as a float
+    for k, v in list(d.items()):
+        if isinstance(v, str):
+            try:
+                d[k] = float(v) if re.fullmatch(r"[+-]?\d+(\.\d*)?[eE][+-]?\d+", v) else v
+            except ValueError:
+                pass
+    return d
+
+
+def load_config(env="local", config_dir="config"):
+    """base.yaml merged with {env}.yaml, env overriding base (train.py:443-453)."""
+    with open(os.path.join(config_dir, "base.yaml")) as f:
+        cfg = Config(_fix_scalars(yaml.safe_load(f) or {}))
+    env_path = os.path.join(config_dir, f"{env}.yaml")
+    if os.path.exists(env_path):
+        with open(env_path) as f:
+            cfg.update(_fix_scalars(yaml.safe_load(f) or {}))
+    return cfg
+
+
+# ---------------------------------------------------------------------- loss (train.py:44-55)
+def _kind_of(loss) -> int:
+    if isinstance(loss, str):
+        return RECON_KINDS[loss]
+    if loss in _CALLABLE_KINDS:
+        return _CALLABLE_KINDS[loss]
+    raise ValueError("reconstruction loss must be one of F.l1_loss, F.mse_loss, F.binary_cross_entropy, "
+                     "F.binary_cross_entropy_with_logits or 'l1' | 'mse' | 'bce' | 'bce_logits'")
+
+
+class _ElboLoss(torch.autograd.Function):
+    """(recon_sum + kl_weight * KL) / N with the gradient of the reconstruction term produced
+    in the same pass that computes it."""
+
+    @staticmethod
+    def forward(ctx, recon, target, mu, logvar, kind, kl_weight):
+        recon, target = recon.contiguous(), target.contiguous()
+        mu, logvar = mu.contiguous(), logvar.contiguous()
+        n, batch = recon.numel(), recon.size(0)
+        s = _lib.current_stream()
+        grid = _lib.call("vae_recon_loss_grid", n)
+        partial = torch.empty(grid, device=recon.device)
+        need_grad = ctx.needs_input_grad[0]
+        grad = torch.empty_like(recon) if need_grad else None
+        _lib.call("vae_recon_loss_fwd_bwd", recon.data_ptr(), target.data_ptr(), _lib.ptr(grad), partial.data_ptr(), n,
+                  kind, 1.0 / batch, s)
+        nl = mu.numel()
+        kgrid = _lib.call("vae_reparam_grid", nl)
+        klp = torch.empty(kgrid, device=recon.device)
+        # eps_in = mu: any valid buffer; with no z output requested only the KL partials are used
+        _lib.call("vae_reparam_kl_fwd", mu.data_ptr(), logvar.data_ptr(), mu.data_ptr(), None, None, None,
+                  klp.data_ptr(), nl, 0, 0, 0, s)
+        out3 = torch.empty(3, device=recon.device)
+        _lib.call("vae_elbo_combine", partial.data_ptr(), grid, klp.data_ptr(), kgrid, float(kl_weight), 1.0 / batch,
+                  out3.data_ptr(), s)
+        ctx.save_for_backward(grad, mu, logvar)
+        ctx.kl_scale = float(kl_weight) / batch
+        ctx.parts = out3
+        return out3[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        grad, mu, logvar = ctx.saved_tensors
+        d_recon = grad * g if grad is not None else None
+        nl = mu.numel()
+        dmu, dlv = torch.empty_like(mu), torch.empty_like(logvar)
+        _lib.call("vae_reparam_kl_bwd", None, mu.data_ptr(), logvar.data_ptr(), mu.data_ptr(), None, None, ctx.kl_scale,
+                  dmu.data_ptr(), dlv.data_ptr(), None, nl, mu.size(-1), 0, 0, 0, _lib.current_stream())
+        return d_recon, None, dmu * g, dlv * g, None, None
+
+
+def vae_loss(input, target, mu: torch.Tensor, logvar: torch.Tensor, loss: Callable, lpips_fn, config):
+    """reference signature (train.py:44).  `loss` selects the reconstruction term."""
+    pw = float(getattr(config, "percep_weight", 0.0) or 0.0)
+    if pw != 0.0 and lpips_fn is not None:
+        raise NotImplementedError("the LPIPS perceptual term is outside the MI355X hot path: set percep_weight: 0")
+    if not input.is_cuda:
+        raise RuntimeError("vae_loss runs on the GPU only (no CPU fallback)")
+    return _ElboLoss.apply(input, target, mu, logvar, _kind_of(loss), float(config.kl_weight))
+
+
+def l1_kl_percep_loss(recons, inputs, mu, logvar, config, LPIPS_FN=None):
+    """reference signature (train.py:54-55)."""
+    return vae_loss(recons, inputs, mu, logvar, F.l1_loss, LPIPS_FN, config)
+
+
+def recon_kind_from_config(config) -> int:
+    return RECON_KINDS[getattr(config, "recon_loss", "l1") if "recon_loss" in config else "l1"]
+
+
+# ---------------------------------------------------------------------- train / val step
+def train_step(model, optimizer, inputs, config, eps=None, keep_masks=None, max_norm=1.0):
+    """The reference's loop body, in its order (train.py:327-339): forward, zero_grad, loss,
+    backward, clip_grad_norm_(1.0), optimizer.step().  Goes through torch autograd (the model
+    and the loss are one autograd node each).  Returns the loss as a 0-dim device tensor (the
+    caller decides when to .item() it)."""
+    recons, mu, logvar = model(inputs, eps, keep_masks)
+    optimizer.zero_grad()
+    kind = recon_kind_from_config(config)
+    loss = _ElboLoss.apply(recons, inputs, mu, logvar, kind, float(config.kl_weight))
+    loss.backward()
+    torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=max_norm)
+    optimizer.step()
+    return loss.detach()
+
+
+def val_step(model, inputs, config, eps=None):
+    """The reference's validation body (train.py:350-353): eval-mode forward + the same loss.
+    Like the reference, eps is still sampled in eval mode (vae.py:108-111)."""
+    with torch.no_grad():
+        recons, mu, logvar = model(inputs, eps)
+        kind = recon_kind_from_config(config)
+        return _ElboLoss.apply(recons, inputs, mu, logvar, kind, float(config.kl_weight))
+
+
+class FusedStep:
+    """The same train step without the autograd engine: forward, fused loss+dloss, backward in
+    stages (so a data-parallel reducer can overlap the all-reduce of finished stages with the
+    rest of the backward), then clip + AdamW.  Numerically identical to train_step()."""
+
+    def __init__(self, model, optimizer, config, reducer=None, max_norm=1.0):
+        self.model, self.optimizer, self.config, self.reducer, self.max_norm = model, optimizer, config, reducer, max_norm
+        self.kind = recon_kind_from_config(config)
+        self.kl_weight = float(config.kl_weight)
+        self._grad_views = None
+        self._bufs = {}
+
+    def _buffers(self, recon, dev):
+        key = tuple(recon.shape)
+        if key not in self._bufs:
+            n = recon.numel()
+            grid = _lib.call("vae_recon_loss_grid", n)
+            self._bufs[key] = (torch.empty_like(recon), torch.empty(grid, device=dev), torch.empty(3, device=dev), grid)
+        return self._bufs[key]
+
+    def __call__(self, inputs, eps=None, keep_masks=None):
+        m = self.model
+        recon, mu, logvar, state = m.forward_raw(inputs, eps, keep_masks)
+        batch = inputs.size(0)
+        d_recon, partial, out3, grid = self._buffers(recon, inputs.device)
+        s = _lib.current_stream()
+        _lib.call("vae_recon_loss_fwd_bwd", recon.data_ptr(), inputs.data_ptr(), d_recon.data_ptr(), partial.data_ptr(),
+                  recon.numel(), self.kind, 1.0 / batch, s)
+        klp, nkl = m.kl_partials(state)
+        _lib.call("vae_elbo_combine", partial.data_ptr(), grid, klp, nkl, self.kl_weight, 1.0 / batch, out3.data_ptr(), s)
+        kl_scale = self.kl_weight / batch
+        if self.reducer is None:
+            m.backward_raw(state, d_recon, None, None, kl_scale, -1)
+        else:
+            for stage in (0, 1, 2):
+                m.backward_raw(state, d_recon, None, None, kl_scale, stage)
+                self.reducer.stage_done(stage)
+            self.reducer.wait()
+        m._release_workspace(state["batch"], state["ws"])
+        if self._grad_views is None or self._grad_views[0].data_ptr() != m.flat_grads.data_ptr():
+            self._grad_views = m.grad_views()
+        if hasattr(self.optimizer, "step_flat"):
+            self.optimizer.step_flat(m, self.max_norm)
+        else:
+            for p, g in zip(m._ordered_params(), self._grad_views):
+                p.grad = g
+            torch.nn.utils.clip_grad_norm_(m.parameters(), max_norm=self.max_norm)
+            self.optimizer.step()
+        return out3[0]
