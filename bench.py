@@ -1,0 +1,213 @@
+"""Headline benchmark: training images/sec of the conv-VAE hot path on N MI355X GPUs.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2_1gpu]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step is one full train step on one synthetic batch already resident in HBM: forward,
+ELBO loss (+ its gradient), backward, global-norm clip, AdamW, bf16 weight repack -- the
+reference's loop body (vae/training/train.py:327-339) -- at BASELINE config 2
+(VAEConv(3,3,128,0.1,32), batch 512 per GPU, bf16 matrix-core operands).  With N > 1 every rank
+runs the same per-GPU batch (weak scaling) and gradients are averaged by a bucketed RCCL
+all-reduce overlapped with the backward pass.
+
+Prints ONE JSON line (rank 0).  Besides the contract fields it carries
+  roofline     : the kernel with the largest share of a step, timed with HIP events on its
+                 own stream in a separate instrumented pass of the same workload
+  kernels      : the same measurement for every instrumented kernel
+  cpu_baseline : the CPU oracle's train step (config 1: batch 64, fp32) on this host's cores
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS_BF16 = 2500.0     # dense bf16 MFMA peak of one MI355X
+PEAK_HBM_GBS = 8000.0         # HBM3E peak of one MI355X
+
+
+def train_flops_per_image(in_ch, latent, S):
+    """algorithmic conv/linear FLOPs of one train step per image: 3 x 2 x forward MACs, minus the
+    input-gradient of the first conv (the images need no gradient)."""
+    enc = [(in_ch, 64, S), (64, 64, S), (64, 128, S // 2), (128, 128, S // 2), (128, 256, S // 4),
+           (256, 256, S // 4), (256, 256, S // 8), (256, 256, S // 8)]
+    macs = sum(ci * co * 9 * h * h for ci, co, h in enc)
+    F = 256 * (S // 8) ** 2
+    macs += 2 * F * latent + latent * F
+    macs += 256 * 128 * 4 * (S // 8) ** 2 + 128 * 64 * 4 * (S // 4) ** 2 + 64 * 64 * 4 * (S // 2) ** 2
+    macs += 64 * 3 * S * S
+    first = in_ch * 64 * 9 * S * S
+    return 6 * macs - 2 * first
+
+
+def profile_pass(step_fn, batches, nsteps=3):
+    """instrumented pass: per-kernel HIP-event timings aggregated by the library."""
+    from vae_amd import _lib
+    _lib.call("vae_prof_start", 1 << 14)
+    for i in range(nsteps):
+        step_fn(batches[i % len(batches)])
+    rows = 128
+    names = ctypes.create_string_buffer(64 * rows)
+    launches = (ctypes.c_int * rows)()
+    ms = (ctypes.c_double * rows)()
+    fl = (ctypes.c_double * rows)()
+    by = (ctypes.c_double * rows)()
+    n = _lib.call("vae_prof_stop", names, launches, ms, fl, by, rows)
+    out = []
+    for k in range(min(n, rows)):
+        name = names.raw[64 * k:64 * (k + 1)].split(b"\0")[0].decode()
+        t = ms[k] * 1e-3
+        mfma = name.startswith("gemm_")
+        rec = {"kernel": name, "launches_per_step": launches[k] / nsteps, "ms_per_step": ms[k] / nsteps,
+               "avg_us": 1e3 * ms[k] / max(launches[k], 1), "bound": "mfma" if mfma else "hbm"}
+        if mfma:
+            rec.update(achieved=fl[k] / t / 1e12 if t > 0 else 0.0, peak=PEAK_TFLOPS_BF16, unit="TFLOP/s")
+        else:
+            rec.update(achieved=by[k] / t / 1e9 if t > 0 else 0.0, peak=PEAK_HBM_GBS, unit="GB/s")
+        rec["frac"] = rec["achieved"] / rec["peak"]
+        rec["gbs"] = by[k] / t / 1e9 if t > 0 else 0.0
+        out.append(rec)
+    out.sort(key=lambda r: -r["ms_per_step"])
+    return out
+
+
+def cpu_baseline(budget_s=15.0):
+    """the CPU oracle's full train step at BASELINE config 1 (batch 64, fp32), timed on this host."""
+    from oracle import vae_oracle as O
+    torch.manual_seed(1337)
+    sd = O.construct_state(3, 3, 128, 0.1, 32)
+    opt = O.new_opt_state(sd)
+    g = torch.Generator().manual_seed(1337)
+    x = torch.rand(64, 3, 32, 32, generator=g)
+    shapes = [(64, 64, 32, 32), (64, 128, 16, 16), (64, 256, 8, 8), (64, 256, 4, 4)]
+
+    def one():
+        eps = torch.randn(64, 128, generator=g)
+        masks = [(torch.rand(s, generator=g) >= 0.1).to(torch.uint8) for s in shapes]
+        O.train_step(x, sd, opt, eps, "l1", 1.0, 0.1, masks)
+
+    one(); one()                                   # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < budget_s or n < 5:
+        one()
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": 64 * n / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"config 1 (VAEConv(3,3,128,0.1,32), batch 64, fp32, full train step) x {n} steps in {dt:.1f} s; "
+                      f"host has {os.cpu_count()} logical CPUs",
+            "ms_per_step": 1e3 * dt / n}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="cfg2_1gpu")
+    ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch size")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--torch-optimizer", action="store_true", help="torch.optim.AdamW + clip_grad_norm_ instead of the fused kernel")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    from vae_amd import _lib
+    from vae_amd.dp import BucketedReducer, broadcast_state, stage_ranges
+    from vae_amd.optim import FlatAdamW
+    from vae_amd.train import FusedStep, load_config
+    from vae_amd.vae import VAEConv
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs one process per GPU: launch with "
+                             f"python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} "
+                             f"--master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    _lib.load()
+
+    conf = load_config(args.config, os.path.join(ROOT, "config"))
+    batch = args.batch or int(conf.batch_size)
+    S, Lat, Cin = int(conf.image_size), int(conf.latent_dims), int(conf.num_channels)
+    torch.manual_seed(int(conf.seed))
+    model = VAEConv(Cin, 3, Lat, float(conf.p_dropout), S).to(dev).train()
+    model.rng_seed, model.rank = int(conf.seed), rank
+    broadcast_state(model)
+    if args.torch_optimizer:
+        opt = torch.optim.AdamW(model.parameters(), lr=float(conf.lr))
+    else:
+        opt = FlatAdamW(model, lr=float(conf.lr))
+    reducer = None
+    if world > 1:
+        reducer = BucketedReducer(model.flat_grads, stage_ranges(model._offsets, model.flat_grads.numel()))
+    step = FusedStep(model, opt, conf, reducer)
+    g = torch.Generator(device=dev).manual_seed(int(conf.seed) + rank)
+    batches = [torch.rand(batch, Cin, S, S, device=dev, generator=g) for _ in range(8)]
+
+    for i in range(args.warmup):
+        step(batches[i % 8])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(batches[i % 8])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    final_loss = loss.item()
+
+    kernels = None
+    if not args.no_kernel_profile:
+        plain = FusedStep(model, opt, conf, None)        # no collectives in the instrumented pass
+        kernels = profile_pass(plain, batches)
+    if rank == 0:
+        ips = world * batch * args.steps / elapsed
+        fpi = train_flops_per_image(Cin, Lat, S)
+        out = {
+            "metric": "training images/sec (whole node)", "value": ips, "unit": "images/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{args.config}: VAEConv({Cin},3,{Lat},{float(conf.p_dropout)},{S}) full train step "
+                                   f"(fwd + {conf.recon_loss}/KL loss + bwd + clip + AdamW), batch {batch} per GPU",
+                       "global_batch": world * batch, "parallelism": f"dp{world}"},
+            "model_tflops": ips * fpi / 1e12,
+            "model_mfma_frac": ips * fpi / 1e12 / (PEAK_TFLOPS_BF16 * world),
+            "final_loss": final_loss,
+        }
+        if kernels:
+            top = kernels[0]
+            out["roofline"] = {"kernel": top["kernel"], "bound": top["bound"], "achieved": top["achieved"],
+                               "peak": top["peak"], "unit": top["unit"], "frac": top["frac"], "traffic": None,
+                               "avg_us": top["avg_us"], "launches_per_step": top["launches_per_step"]}
+            out["kernels"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in kernels[:24]]
+            out["kernel_ms_per_step_sum"] = sum(r["ms_per_step"] for r in kernels)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

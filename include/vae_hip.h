@@ -41,6 +41,15 @@ extern "C" {
 int vae_version(void);
 const char* vae_last_error(void);
 
+/* Optional measurement aid (no counterpart in the reference, which has no profiler): between
+ * vae_prof_start and vae_prof_stop every GEMM / norm / loss launch is bracketed by HIP events
+ * on its own stream.  vae_prof_stop synchronises the device and returns one row per kernel
+ * name: launches, summed milliseconds, and the summed ALGORITHMIC flops / bytes the launchers
+ * declared (names: 64 bytes per row).  Returns the number of distinct kernels. */
+int vae_prof_start(int max_launches);
+int vae_prof_stop(char* names, int* launches, double* total_ms, double* flops, double* bytes,
+                  int max_rows);
+
 /* ---- ELBO loss: vae_loss(), vae/training/train.py:44-51 -------------------------------- */
 /* number of workgroups (= length of the `partial` array) the loss kernel uses for n_elems */
 int vae_recon_loss_grid(long n_elems);
@@ -225,6 +234,16 @@ int vae_model_backward(const vae_model_cfg* cfg, const float* params, const void
                        const float* d_recon, const float* recon, const float* mu, const float* logvar,
                        const float* eps_in, const void* const* keep_masks, const float* dmu_ext,
                        const float* dlv_ext, float kl_scale, float* grads, int stage, void* stream);
+
+/* ---- clip_grad_norm_(max_norm) + AdamW.step(), vae/training/train.py:336,338,310, on the flat
+ *      buffers.  grads are first multiplied by grad_mul (1/world_size after a SUM all-reduce);
+ *      max_norm <= 0 disables clipping; partial: vae_adamw_grid(n) floats of scratch;
+ *      grad_norm_out (optional) receives the pre-clip global L2 norm. */
+int vae_adamw_grid(long n);
+int vae_adamw_clip_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n,
+                        float* partial, float grad_mul, float max_norm, float lr, float beta1,
+                        float beta2, float eps, float weight_decay, int step, float* grad_norm_out,
+                        void* stream);
 
 #ifdef __cplusplus
 }

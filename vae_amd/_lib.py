@@ -19,6 +19,8 @@ P = c_void_p
 SIGNATURES = {
     "vae_version": (c_int, []),
     "vae_last_error": (c_char_p, []),
+    "vae_prof_start": (None, [c_int]),
+    "vae_prof_stop": (c_int, [P, P, P, P, P, c_int]),
     "vae_recon_loss_grid": (c_int, [c_long]),
     "vae_recon_loss_fwd_bwd": (None, [P, P, P, P, c_long, c_int, c_float, P]),
     "vae_elbo_combine": (None, [P, c_int, P, c_int, c_float, c_float, P, P]),
@@ -52,6 +54,9 @@ SIGNATURES = {
     "vae_tanh_bwd_rows": (c_int, [c_int]),
     "vae_tanh_bwd": (None, [P, P, P, P, c_int, c_int, P]),
     "vae_nchw_to_nhwc8": (None, [P, P, c_int, c_int, c_int, c_int, P]),
+    "vae_adamw_grid": (c_int, [c_long]),
+    "vae_adamw_clip_step": (None, [P, P, P, P, c_long, P, c_float, c_float, c_float, c_float, c_float,
+                                   c_float, c_float, c_int, P, P]),
     "vae_permute_f32": (None, [P, P, P, P, c_long, P]),
     "vae_cast_bf16": (None, [P, P, c_long, P]),
     "vae_model_param_count": (c_long, [P]),

@@ -1,8 +1,16 @@
-// Version and thread-local error string of libvae_hip.so.
+// Version, thread-local error string, and the optional per-kernel event profiler of
+// libvae_hip.so.
+#include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
 
 #include "../../include/vae_hip.h"
+#include "prof.h"
 
 namespace vae {
 static thread_local char g_err[512] = "";
@@ -12,7 +20,96 @@ void set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+
+// ---------------------------------------------------------------- event profiler
+// Off by default (one branch per launch).  When armed by vae_prof_start, every instrumented
+// launch is bracketed by a pair of pre-created hipEvents on the launch stream; vae_prof_stop
+// synchronises, reads the elapsed times and aggregates them per kernel name together with
+// the algorithmic FLOPs / bytes the launcher declared.  Events are created in
+// vae_prof_start (never inside a launch), so the launch path itself allocates nothing.
+struct ProfRecord {
+    const char* name;
+    double flops, bytes;
+};
+static std::vector<hipEvent_t> g_ev;
+static std::vector<ProfRecord> g_rec;
+static bool g_on = false;
+static size_t g_cap = 0;
+
+bool prof_enabled() { return g_on; }
+
+void prof_begin(const char* name, double flops, double bytes, hipStream_t s) {
+    if (!g_on || g_rec.size() >= g_cap) return;
+    g_rec.push_back({name, flops, bytes});
+    hipEventRecord(g_ev[2 * (g_rec.size() - 1)], s);
+}
+void prof_end(hipStream_t s) {
+    if (!g_on || g_rec.empty() || g_rec.size() > g_cap) return;
+    hipEventRecord(g_ev[2 * (g_rec.size() - 1) + 1], s);
+}
 }  // namespace vae
 
 extern "C" int vae_version(void) { return VAE_HIP_VERSION; }
 extern "C" const char* vae_last_error(void) { return vae::g_err; }
+
+extern "C" int vae_prof_start(int max_launches) {
+    using namespace vae;
+    if (max_launches <= 0 || max_launches > (1 << 20)) {
+        set_error("vae_prof_start: max_launches=%d out of range", max_launches);
+        return 1;
+    }
+    while (g_ev.size() < (size_t)2 * max_launches) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) {
+            set_error("vae_prof_start: hipEventCreate failed");
+            return 2;
+        }
+        g_ev.push_back(e);
+    }
+    g_rec.clear();
+    g_rec.reserve(max_launches);
+    g_cap = max_launches;
+    g_on = true;
+    return 0;
+}
+
+// Writes up to max_rows aggregated rows; returns the number of distinct kernels (or -1).
+// Row i: names[i] (64 bytes each), launches[i], total_ms[i], flops[i], bytes[i] (sums).
+extern "C" int vae_prof_stop(char* names, int* launches, double* total_ms, double* flops, double* bytes,
+                             int max_rows) {
+    using namespace vae;
+    g_on = false;
+    hipDeviceSynchronize();
+    std::map<std::string, int> index;
+    std::vector<std::string> order;
+    std::vector<int> cnt;
+    std::vector<double> ms, fl, by;
+    for (size_t i = 0; i < g_rec.size(); ++i) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, g_ev[2 * i], g_ev[2 * i + 1]) != hipSuccess) continue;
+        auto it = index.find(g_rec[i].name);
+        int k;
+        if (it == index.end()) {
+            k = (int)order.size();
+            index[g_rec[i].name] = k;
+            order.push_back(g_rec[i].name);
+            cnt.push_back(0); ms.push_back(0); fl.push_back(0); by.push_back(0);
+        } else {
+            k = it->second;
+        }
+        cnt[k] += 1; ms[k] += t; fl[k] += g_rec[i].flops; by[k] += g_rec[i].bytes;
+    }
+    g_rec.clear();
+    const int n = (int)order.size();
+    for (int k = 0; k < n && k < max_rows; ++k) {
+        if (names) {
+            strncpy(names + 64 * k, order[k].c_str(), 63);
+            names[64 * k + 63] = 0;
+        }
+        if (launches) launches[k] = cnt[k];
+        if (total_ms) total_ms[k] = ms[k];
+        if (flops) flops[k] = fl[k];
+        if (bytes) bytes[k] = by[k];
+    }
+    return n;
+}

@@ -17,6 +17,7 @@
 // ([split][m][tap][n], plain 16-byte stores, deterministic) and vae_reduce_slabs folds the slabs
 // into the gradient tensor in the reference layout.
 #include "common.h"
+#include "prof.h"
 #include "../../include/vae_hip.h"
 
 namespace vae {
@@ -231,9 +232,17 @@ template <int MODE>
 static int launch_nt(const GemmNT& p, int nsplit, hipStream_t s) {
     const bool m128 = p.M % 128 == 0, n128 = p.N % 128 == 0;
     dim3 block(256);
+    // algorithmic work: every k row of P and Q read once, the slabs written once
+    const double ntap = MODE == G_CONV3_C8 ? 27.0 / 64.0 : (double)p.taps;   // 3 real channels x 9 taps of the 2 x 64 columns
+    const double flops = 2.0 * p.M * p.N * ntap * p.Ktot;
+    const double bytes = 2.0 * p.Ktot * ((double)p.M * (MODE == G_CONVT ? 4 : 1) + (MODE == G_CONV3_C8 ? 8 : p.N)) +
+                         4.0 * nsplit * p.taps * p.M * p.N;
 #define GO(BM_, BN_)                                                                          \
     {                                                                                         \
         dim3 grid(p.N / BN_, p.M / BM_, p.taps * nsplit);                                     \
+        static char name[64] = "";                                                            \
+        if (!name[0]) snprintf(name, sizeof(name), "gemm_nt_kernel<%d,%d,%d>", BM_, BN_, MODE); \
+        ProfScope prof(name, flops, bytes, s);                                                \
         hipLaunchKernelGGL((gemm_nt_kernel<BM_, BN_, MODE>), grid, block, 0, s, p);           \
     }
     if (m128 && n128) GO(128, 128)
@@ -258,6 +267,9 @@ extern "C" int vae_wgrad_ksplit(int M, int N, int taps, long Ktot) {
     if (s > maxs) s = maxs;
     if (s < 1) s = 1;
     if (s > 256) s = 256;
+    // normalise: chunks are multiples of 64 k rows and no split may be empty
+    const long chunk = ((Ktot + s - 1) / s + 63) / 64 * 64;
+    s = (Ktot + chunk - 1) / chunk;
     return (int)s;
 }
 
@@ -309,6 +321,7 @@ extern "C" int vae_reduce_slabs(const float* slab, int nsplit, long slab_stride,
     if (int e = make_map(mp, dims4, strides4, base, "vae_reduce_slabs")) return e;
     const long n = dims4[0] * dims4[1] * dims4[2] * dims4[3];
     const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    ProfScope prof("reduce_slabs_kernel", 0.0, 4.0 * n * (nsplit + 1), (hipStream_t)stream);
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, slab, nsplit,
                        slab_stride, out, n, mp, accumulate);
     VAE_LAUNCH_CHECK("reduce_slabs_kernel");
@@ -322,6 +335,7 @@ extern "C" int vae_pack_bf16(const float* src, void* dst, const long* dims4, con
     if (int e = make_map(mp, dims4, strides4, base, "vae_pack_bf16")) return e;
     const long n = dims4[0] * dims4[1] * dims4[2] * dims4[3];
     const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    ProfScope prof("pack_bf16_kernel", 0.0, 6.0 * n, (hipStream_t)stream);
     hipLaunchKernelGGL(pack_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n, mp);
     VAE_LAUNCH_CHECK("pack_bf16_kernel");
     return 0;

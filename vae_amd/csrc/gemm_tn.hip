@@ -21,6 +21,7 @@
 // pixel per accumulator -> 8-byte (bf16) / 16-byte (fp32) NHWC stores, and per-channel batch
 // statistics reduce over the 16 lanes that share (lane >> 4).
 #include "common.h"
+#include "prof.h"
 #include "../../include/vae_hip.h"
 
 namespace vae {
@@ -42,6 +43,7 @@ struct GemmTN {
     int ldo;              // output row stride in elements
     int split;            // E_F32_SPLIT: columns per half
     int Co;               // E_CONVT: channels per tap
+    double flops, bytes;  // algorithmic work of this launch (profiling only)
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -278,6 +280,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
 template <int BM, int BN, int BK, int WAVES_M, int AMODE, int EPI>
 static int launch_one(const GemmTN& p, hipStream_t s) {
     dim3 grid((p.M + BM - 1) / BM, (p.N + BN - 1) / BN);
+    static char name[64] = "";
+    if (!name[0]) snprintf(name, sizeof(name), "gemm_tn_kernel<%d,%d,%d,%d,%d,%d>", BM, BN, BK, WAVES_M, AMODE, EPI);
+    ProfScope prof(name, p.flops, p.bytes, s);
     hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, BK, WAVES_M, AMODE, EPI>), grid, dim3(256), 0, s, p);
     VAE_LAUNCH_CHECK("gemm_tn_kernel");
     return 0;
@@ -316,6 +321,8 @@ extern "C" int vae_conv3x3_gemm(const void* x, const void* w_packed, const float
     VAE_CHECK(H < 65536 && W < 65536, "vae_conv3x3_gemm: H, W must be < 65536");
     VAE_CHECK(Cin % 64 == 0, "vae_conv3x3_gemm: Cin=%d must be a multiple of 64 (use the im2col path below that)", Cin);
     p.M = n_img * H * W; p.N = Cout; p.K = 9 * Cin; p.H = H; p.W = W; p.C = Cin; p.ldo = Cout;
+    p.flops = 2.0 * p.M * p.N * p.K;
+    p.bytes = 2.0 * ((double)p.M * Cin + (double)p.N * p.K + (double)p.M * Cout);
     if (int e = check_common(p, 64, "vae_conv3x3_gemm")) return e;
     return launch_bk64<A_CONV3, E_BF16>(p, (hipStream_t)stream);
 }
@@ -329,6 +336,8 @@ extern "C" int vae_conv3x3_c8_gemm(const void* x8, const void* w_packed, const f
     VAE_CHECK(n_img > 0 && H > 0 && W > 0 && (long)n_img * H * W < (1L << 31) && H < 65536 && W < 65536,
               "vae_conv3x3_c8_gemm: bad geometry n=%d H=%d W=%d", n_img, H, W);
     p.M = n_img * H * W; p.N = Cout; p.K = 128; p.H = H; p.W = W; p.C = 8; p.ldo = Cout;
+    p.flops = 2.0 * p.M * p.N * 27.0;      // 3 real input channels x 9 taps
+    p.bytes = 2.0 * ((double)p.M * 8 + (double)p.N * p.K + (double)p.M * Cout);
     if (int e = check_common(p, 64, "vae_conv3x3_c8_gemm")) return e;
     return launch_bk64<A_CONV3_C8, E_BF16>(p, (hipStream_t)stream);
 }
@@ -342,6 +351,8 @@ extern "C" int vae_convt2x2_fwd_gemm(const void* x, const void* w_packed, const 
     VAE_CHECK(n_img > 0 && H > 0 && W > 0 && (long)n_img * H * W * 4 < (1L << 31), "vae_convt2x2_fwd_gemm: bad geometry");
     VAE_CHECK(Cin % 64 == 0 && Cout % 4 == 0, "vae_convt2x2_fwd_gemm: Cin=%d must be a multiple of 64, Cout=%d of 4", Cin, Cout);
     p.M = n_img * H * W; p.N = 4 * Cout; p.K = Cin; p.lda = Cin; p.H = H; p.W = W; p.Co = Cout;
+    p.flops = 2.0 * p.M * p.N * p.K;
+    p.bytes = 2.0 * ((double)p.M * Cin + (double)p.N * p.K + (double)p.M * p.N);
     if (int e = check_common(p, 64, "vae_convt2x2_fwd_gemm")) return e;
     return launch_bk64<A_PLAIN, E_CONVT>(p, (hipStream_t)stream);
 }
@@ -353,6 +364,8 @@ extern "C" int vae_convt2x2_dgrad_gemm(const void* dy, const void* w_packed, voi
     VAE_CHECK(n_img > 0 && H > 0 && W > 0 && (long)n_img * H * W * 4 < (1L << 31), "vae_convt2x2_dgrad_gemm: bad geometry");
     VAE_CHECK(Cout % 64 == 0, "vae_convt2x2_dgrad_gemm: Cout=%d must be a multiple of 64", Cout);
     p.M = n_img * H * W; p.N = Cin; p.K = 4 * Cout; p.H = H; p.W = W; p.C = Cout; p.ldo = Cin;
+    p.flops = 2.0 * p.M * p.N * p.K;
+    p.bytes = 2.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N);
     if (int e = check_common(p, 64, "vae_convt2x2_dgrad_gemm")) return e;
     return launch_bk64<A_CONVT_DGRAD, E_BF16>(p, (hipStream_t)stream);
 }
@@ -364,6 +377,8 @@ extern "C" int vae_linear_gemm(const void* a, const void* w, const float* bias, 
     p.A = (const bf16_t*)a; p.B = (const bf16_t*)w; p.bias = bias; p.out = out; p.out2 = out2;
     p.stat_sum = stat_sum; p.stat_sq = stat_sq;
     p.M = M; p.N = N; p.K = K; p.lda = K; p.ldo = N;
+    p.flops = 2.0 * M * N * K;
+    p.bytes = 2.0 * ((double)M * K + (double)N * K) + (epilogue >= VAE_EPI_F32 ? 4.0 : 2.0) * M * N;
     hipStream_t s = (hipStream_t)stream;
     if (K % 64 != 0) {
         VAE_CHECK(epilogue == VAE_EPI_BF16, "vae_linear_gemm: K=%d not a multiple of 64 is only supported with the bf16 epilogue", K);

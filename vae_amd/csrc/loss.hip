@@ -5,6 +5,7 @@
 // partials (in double) into  loss = (recon_sum + kl_weight * kl_sum) / batch.
 // HBM-bound: 12 algorithmic bytes per element (two fp32 reads, one fp32 write).
 #include "common.h"
+#include "prof.h"
 #include "../../include/vae_hip.h"
 
 namespace vae {
@@ -123,6 +124,7 @@ extern "C" int vae_recon_loss_fwd_bwd(const float* recon, const float* target, f
               "vae_recon_loss_fwd_bwd: pointers must be 16-byte aligned");
     const int grid = vae_recon_loss_grid(n_elems);
     hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(grad ? "recon_loss_kernel<fwd+bwd>" : "recon_loss_kernel<fwd>", 0.0, (grad ? 12.0 : 8.0) * n_elems, s);
 #define LAUNCH(K)                                                                              \
     if (grad)                                                                                  \
         hipLaunchKernelGGL((recon_loss_kernel<K, true>), dim3(grid), dim3(256), 0, s, recon,   \

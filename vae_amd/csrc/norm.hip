@@ -8,6 +8,7 @@
 //             no full-resolution activation is stored): pass 1 reduces sum(g) and sum(g*xhat) per
 //             channel, pass 2 writes dy = scale * (g - mean(g) - xhat * mean(g*xhat)).
 #include "common.h"
+#include "prof.h"
 #include "../../include/vae_hip.h"
 
 namespace vae {
@@ -531,6 +532,8 @@ extern "C" int vae_bn_act_fwd(const void* y, const float* scale, const float* sh
     const DropCfg d = make_drop(p_drop, keep_mask, seed, step, stream_id, rank);
     const long items = (long)n_img * H * W / (pool ? 4 : 1) * (C / 8);
     hipStream_t s = (hipStream_t)stream;
+    const double elems = (double)n_img * H * W * C;
+    ProfScope prof(pool ? "bn_act_fwd_kernel<pool>" : "bn_act_fwd_kernel", 0.0, 2.0 * elems * (pool ? 1.25 : 2.0), s);
     if (pool) hipLaunchKernelGGL(bn_act_fwd_kernel<true>, dim3(elem_grid(items)), dim3(256), 0, s, (const bf16_t*)y, scale, shift, (bf16_t*)out, g, d);
     else hipLaunchKernelGGL(bn_act_fwd_kernel<false>, dim3(elem_grid(items)), dim3(256), 0, s, (const bf16_t*)y, scale, shift, (bf16_t*)out, g, d);
     VAE_LAUNCH_CHECK("bn_act_fwd_kernel");
@@ -558,6 +561,10 @@ extern "C" int vae_bn_act_bwd(const void* gin, const void* y, const float* scale
     hipStream_t s = (hipStream_t)stream;
     const bf16_t* gi = (const bf16_t*)gin;
     const bf16_t* yy = (const bf16_t*)y;
+    const double elems = (double)n_img * H * W * C;
+    // both passes together: y read twice, gin read twice, dy written once
+    ProfScope prof(pool ? "bn_act_bwd(reduce+apply)<pool>" : "bn_act_bwd(reduce+apply)", 0.0,
+                   2.0 * elems * (2.0 + 2.0 * (pool ? 0.25 : 1.0) + 1.0), s);
     if (pool) hipLaunchKernelGGL((bn_act_bwd_kernel<true, 0>), dim3(nb), dim3(256), 0, s, gi, yy, scale, shift, mean, rstd, sums, inv_count, partial, (bf16_t*)dy, g, d);
     else hipLaunchKernelGGL((bn_act_bwd_kernel<false, 0>), dim3(nb), dim3(256), 0, s, gi, yy, scale, shift, mean, rstd, sums, inv_count, partial, (bf16_t*)dy, g, d);
     VAE_LAUNCH_CHECK("bn_act_bwd_kernel<0>");
@@ -578,6 +585,7 @@ extern "C" int vae_head_fwd(const void* y, const float* scale, const float* shif
     const long npix = (long)n_img * H * W;
     const int grid = elem_grid(npix * 8);
     hipStream_t s = (hipStream_t)stream;
+    ProfScope prof("head_fwd_kernel", 2.0 * npix * 64 * Cout, npix * (128.0 + 4.0 * Cout), s);
 #define GO(CO) hipLaunchKernelGGL(head_fwd_kernel<CO>, dim3(grid), dim3(256), 0, s, (const bf16_t*)y, scale, shift, w, b, recon, npix, H * W)
     switch (Cout) { case 1: GO(1); break; case 2: GO(2); break; case 3: GO(3); break; default: GO(4); }
 #undef GO
@@ -604,6 +612,7 @@ extern "C" int vae_head_bwd(const float* drecon, const float* recon, const void*
     const float inv_count = (float)(1.0 / (double)npix);
     hipStream_t s = (hipStream_t)stream;
     const bf16_t* yy = (const bf16_t*)y;
+    ProfScope prof("head_bwd(reduce+apply)", 0.0, npix * (2 * 128.0 + 2 * 8.0 * Cout + 128.0), s);
 #define GO(CO, PASS, NB) hipLaunchKernelGGL((head_bwd_kernel<CO, PASS>), dim3(NB), dim3(256), 0, s, drecon, recon, yy, scale, shift, mean, rstd, w, sums, inv_count, partial, (bf16_t*)dy, npix, H * W)
     switch (Cout) { case 1: GO(1, 0, nb); break; case 2: GO(2, 0, nb); break; case 3: GO(3, 0, nb); break; default: GO(4, 0, nb); }
     VAE_LAUNCH_CHECK("head_bwd_kernel<0>");

@@ -9,6 +9,7 @@
 // HBM-bound; forward moves 12 algorithmic bytes per latent element (mu, logvar in, z out),
 // eps is regenerated from the counter in the backward instead of being stored.
 #include "common.h"
+#include "prof.h"
 #include "../../include/vae_hip.h"
 
 namespace vae {
@@ -167,6 +168,7 @@ extern "C" int vae_reparam_kl_fwd(const float* mu, const float* logvar, const fl
               "vae_reparam_kl_fwd: pointers must be 16-byte aligned");
     VAE_CHECK(n_elems < (1L << 34), "vae_reparam_kl_fwd: n_elems too large for a 32-bit block counter");
     const int grid = vae_reparam_grid(n_elems);
+    ProfScope prof("reparam_kl_fwd_kernel", 0.0, n_elems * (8.0 + (eps_in ? 4.0 : 0.0) + (z_f32 ? 4.0 : 0.0) + (z_bf16 ? 2.0 : 0.0) + (eps_out ? 4.0 : 0.0)), (hipStream_t)stream);
     hipLaunchKernelGGL(reparam_kl_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, mu,
                        logvar, eps_in, z_f32, (bf16_t*)z_bf16, eps_out, kl_partial, n_elems, seed,
                        step, rank);

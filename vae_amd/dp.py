@@ -1,0 +1,84 @@
+"""Data-parallel gradient exchange: bucketed all-reduce of the flat gradient buffer over
+RCCL (torch.distributed backend "nccl" on ROCm), overlapped with the backward pass.
+
+The reference is single-process (no torch.distributed call anywhere); this is the batch
+data-parallel step the MI355X build adds.  Parameters, optimizer state and BatchNorm running
+stats are replicated; BatchNorm batch statistics stay per rank (the single-process semantics
+at the local batch).  The backward pass finishes layers in three stages (decoder + latent
+heads, conv4+conv3, conv2+conv1); each stage's slice of the flat gradient buffer is contiguous,
+so its buckets are plain views (no copy) and are all-reduced on a side stream while the next
+stage computes."""
+from __future__ import annotations
+
+from typing import List, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def stage_ranges(offsets: Sequence[Tuple[int, int]], total: int) -> List[Tuple[int, int]]:
+    """[begin, end) of the flat buffer finished by backward stage 0, 1, 2.
+    offsets: (offset, numel) of the 52 parameters in state_dict order:
+    0-15 conv1+conv2, 16-31 conv3+conv4, 32-51 latent heads + decoder."""
+    s1, s0 = offsets[16][0], offsets[32][0]
+    return [(s0, total), (s1, s0), (0, s1)]
+
+
+def split_buckets(begin: int, end: int, bucket_elems: int) -> List[Tuple[int, int]]:
+    out = []
+    a = begin
+    while a < end:
+        b = min(end, a + bucket_elems)
+        out.append((a, b))
+        a = b
+    return out
+
+
+class BucketedReducer:
+    """all-reduce (mean) of `flat_grads` in per-stage buckets."""
+
+    def __init__(self, flat_grads: torch.Tensor, ranges: Sequence[Tuple[int, int]], bucket_bytes: int = 16 << 20,
+                 group=None):
+        self.flat = flat_grads
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.buckets = [split_buckets(a, b, max(1, bucket_bytes // flat_grads.element_size())) for a, b in ranges]
+        self.cuda = flat_grads.is_cuda
+        self.comm_stream = torch.cuda.Stream() if self.cuda else None
+        self.handles = []
+        backend = dist.get_backend(group) if dist.is_initialized() else ""
+        self.avg_op = backend == "nccl"          # RCCL has ncclAvg; gloo needs SUM then a divide
+
+    def stage_done(self, stage: int):
+        """call right after the kernels of backward stage `stage` were enqueued."""
+        if self.world == 1:
+            return
+        op = dist.ReduceOp.AVG if self.avg_op else dist.ReduceOp.SUM
+        if self.cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(ev)
+                for a, b in self.buckets[stage]:
+                    self.handles.append((dist.all_reduce(self.flat[a:b], op=op, group=self.group, async_op=True), a, b))
+        else:
+            for a, b in self.buckets[stage]:
+                self.handles.append((dist.all_reduce(self.flat[a:b], op=op, group=self.group, async_op=True), a, b))
+
+    def wait(self):
+        """make the current stream wait for every outstanding bucket (and finish the mean)."""
+        for h, a, b in self.handles:
+            h.wait()
+            if not self.avg_op:
+                self.flat[a:b].div_(self.world)
+        self.handles = []
+
+
+def broadcast_state(model, src: int = 0, group=None):
+    """same initial parameters / running stats on every rank."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    dist.broadcast(model.flat_params, src, group=group)
+    dist.broadcast(model._bn_stats, src, group=group)
+    dist.broadcast(model._nbt, src, group=group)
+    model.repack_weights()
