@@ -132,6 +132,23 @@ int vae_wgrad_gemm(const void* P, const void* Q, float* slab, int M, int N, long
  * layout to the parameter's own layout (e.g. Conv2d [Cout][Cin][3][3]). */
 int vae_reduce_slabs(const float* slab, int nsplit, long slab_stride, float* out, const long* dims4,
                      const long* strides4, long base, int accumulate, void* stream);
+/* The same fold walking the slab in ITS order (coalesced) and scattering the results:
+ * out[base + i0*s0+..+i3*s3] (+)= sum_s slab[s*slab_stride + slab_base + q], q row-major over
+ * dims4 (the slab's own dims); tuples with i_d >= limits4[d] (padding) are skipped. */
+int vae_reduce_slabs_scatter(const float* slab, int nsplit, long slab_stride, long slab_base,
+                             float* out, const long* dims4, const long* strides4,
+                             const long* limits4, long base, int accumulate, void* stream);
+/* Many pack / permute jobs in one launch (all weights of the model after an optimizer step). */
+#define VAE_MAX_PACK_JOBS 40
+typedef struct vae_pack_job {
+    const float* src;
+    void* dst;          /* bf16 (f32 = 0) or float (f32 = 1) */
+    long dims[4];       /* row-major index space of src */
+    long strides[4];    /* dst offset = base + sum i_d * strides[d] */
+    long base;
+    int f32;
+} vae_pack_job;
+int vae_multi_pack(const vae_pack_job* jobs, int njobs, void* stream);
 /* dst_bf16[base + i0*s0+i1*s1+i2*s2+i3*s3] = bf16(src[e]): fp32 parameter -> packed bf16 operand */
 int vae_pack_bf16(const float* src, void* dst_bf16, const long* dims4, const long* strides4,
                   long base, void* stream);
@@ -140,8 +157,11 @@ int vae_pack_bf16(const float* src, void* dst_bf16, const long* dims4, const lon
  *      vae/models/vae.py:130-137,35,38,41, and bn3/bn2/bn1 + relu, vae.py:119-121 ------------- */
 /* Folds the GEMM epilogue's per-workgroup sums (rows x fold*C) into scale = gamma*rstd,
  * shift = beta - mean*scale, mean, rstd, and moves running_mean / running_var (momentum 0.1,
- * unbiased variance) when they are given.  use_running = 1: eval mode, stats are not read. */
-int vae_bn_finalize(const float* stat_sum, const float* stat_sq, int rows, int C, int fold,
+ * unbiased variance) when they are given.  use_running = 1: eval mode, stats are not read.
+ * stat_sum / stat_sq must have VAE_STAT_SCRATCH_ROWS more rows than `rows`: with many partial
+ * rows they are first folded into that tail by the whole chip. */
+#define VAE_STAT_SCRATCH_ROWS 32
+int vae_bn_finalize(float* stat_sum, float* stat_sq, int rows, int C, int fold,
                     double count, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, float momentum, float eps, int use_running, float* scale,
                     float* shift, float* mean, float* rstd, void* stream);
@@ -168,12 +188,13 @@ int vae_bn_act_bwd(const void* gin, const void* y, const float* scale, const flo
 int vae_head_fwd(const void* y, const float* scale, const float* shift, const float* w,
                  const float* b, float* recon, int n_img, int H, int W, int Cout, void* stream);
 int vae_head_bwd_blocks(int n_img, int H, int W);
-/* its backward: partial is blocks x (3+Cout)*64 floats; sums = [d gamma1(64) | d beta1(64) |
- * dW[Cout][64] | db (Cout, padded to 64)]; dy [n,H,W,64] bf16 = grad of up1's output. */
+/* its backward: partial is blocks x (3+Cout)*64 floats of scratch; sums = [d gamma1(64) |
+ * d beta1(64)]; sums_head = [dW[Cout][64] | db(Cout)] (Cout*65 floats);
+ * dy [n,H,W,64] bf16 = grad of up1's output. */
 int vae_head_bwd(const float* drecon, const float* recon, const void* y, const float* scale,
                  const float* shift, const float* mean, const float* rstd, const float* w,
-                 float* partial, float* sums, void* dy, int n_img, int H, int W, int Cout,
-                 void* stream);
+                 float* partial, float* sums, float* sums_head, void* dy, int n_img, int H, int W,
+                 int Cout, void* stream);
 /* torch.tanh backward (vae.py:116): dpre = dx*(1-h^2), colpartial [vae_tanh_bwd_rows(rows)][cols]
  * = per-row-group column sums of dpre (fc_up bias gradient). */
 int vae_tanh_bwd_rows(int rows);
@@ -241,8 +262,8 @@ int vae_model_backward(const vae_model_cfg* cfg, const float* params, const void
  *      grad_norm_out (optional) receives the pre-clip global L2 norm. */
 int vae_adamw_grid(long n);
 int vae_adamw_clip_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n,
-                        float* partial, float grad_mul, float max_norm, float lr, float beta1,
-                        float beta2, float eps, float weight_decay, int step, float* grad_norm_out,
+                        float* partial, float grad_mul, float max_norm, double lr, double beta1,
+                        double beta2, double eps, double weight_decay, int step, float* grad_norm_out,
                         void* stream);
 
 #ifdef __cplusplus

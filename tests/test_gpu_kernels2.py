@@ -254,16 +254,17 @@ def test_head_fwd_bwd(L, n, H, W, Co):
     nb = L.call("vae_head_bwd_blocks", n, H, W)
     ncols = (3 + Co) * 64
     partial = torch.full((nb, ncols), float("nan"), device=DEV)
-    sums = torch.full((ncols,), float("nan"), device=DEV)
+    sums = torch.full((128,), float("nan"), device=DEV)
+    sums_head = torch.full((Co * 65,), float("nan"), device=DEV)
     dy = torch.full((n, H, W, C), float("nan"), device=DEV, dtype=torch.bfloat16)
     drd = dr.to(DEV)
     L.call("vae_head_bwd", L.ptr(drd), L.ptr(recon), L.ptr(yd), L.ptr(sc), L.ptr(sh), L.ptr(mean), L.ptr(rstd),
-           L.ptr(wd), L.ptr(partial), L.ptr(sums), L.ptr(dy), n, H, W, Co, L.current_stream())
-    s = sums.cpu()
+           L.ptr(wd), L.ptr(partial), L.ptr(sums), L.ptr(sums_head), L.ptr(dy), n, H, W, Co, L.current_stream())
+    s, sh_ = sums.cpu(), sums_head.cpu()
     assert rel_l2(s[:64], gr.grad) <= 2e-5
     assert rel_l2(s[64:128], br.grad) <= 2e-5
-    assert rel_l2(s[128:128 + Co * 64], wr.grad.view(-1)) <= 2e-5
-    assert rel_l2(s[128 + Co * 64:128 + Co * 64 + Co], bbr.grad) <= 2e-5
+    assert rel_l2(sh_[:Co * 64], wr.grad.view(-1)) <= 2e-5
+    assert rel_l2(sh_[Co * 64:], bbr.grad) <= 2e-5
     check_bf16(from_nhwc(dy), yr.grad, "head bwd", rtol=4e-3)
 
 

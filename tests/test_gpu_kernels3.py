@@ -1,0 +1,101 @@
+"""Parity of the statistics fold with many partial rows, the coalesced slab reducer, the
+one-launch weight packer, the split-K linear GEMM and the fused clip + AdamW step."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import vae_oracle as O
+from golden_util import rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def L():
+    from vae_amd import _lib
+    _lib.load()
+    return _lib
+
+
+@pytest.mark.parametrize("rows,C,fold", [(65, 64, 1), (4096, 64, 1), (300, 64, 4), (1000, 256, 1)])
+def test_bn_finalize_many_rows(L, rows, C, fold):
+    g = torch.Generator().manual_seed(rows + C)
+    ncols = fold * C
+    ps = torch.randn(rows, ncols, generator=g)
+    pq = torch.rand(rows, ncols, generator=g) * 3 + 4
+    count = float(rows * 128 * fold)
+    scratch = L.load().vae_gemm_rows_per_block() and 32
+    psd = torch.cat([ps, torch.full((scratch, ncols), float("nan"))]).to(DEV)
+    pqd = torch.cat([pq, torch.full((scratch, ncols), float("nan"))]).to(DEV)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.rand(C, generator=g)
+    rm, rv = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+    gd, bd, rmd, rvd = gamma.to(DEV), beta.to(DEV), rm.to(DEV), rv.to(DEV)
+    sc, sh, mean, rstd = (torch.empty(C, device=DEV) for _ in range(4))
+    L.call("vae_bn_finalize", L.ptr(psd), L.ptr(pqd), rows, C, fold, count, L.ptr(gd), L.ptr(bd), L.ptr(rmd), L.ptr(rvd),
+           0.1, 1e-5, 0, L.ptr(sc), L.ptr(sh), L.ptr(mean), L.ptr(rstd), L.current_stream())
+    m_ref = ps.double().sum(0).view(fold, C).sum(0) / count
+    v_ref = (pq.double().sum(0).view(fold, C).sum(0) / count - m_ref ** 2).clamp_min(0)
+    assert rel_l2(mean.cpu(), m_ref) <= 1e-5
+    assert rel_l2(rstd.cpu(), 1 / torch.sqrt(v_ref + 1e-5)) <= 1e-5
+    assert rel_l2(rmd.cpu(), 0.9 * rm + 0.1 * m_ref) <= 1e-5
+    assert rel_l2(rvd.cpu(), 0.9 * rv + 0.1 * v_ref * count / (count - 1)) <= 1e-5
+
+
+def test_reduce_slabs_scatter_and_multi_pack(L):
+    g = torch.Generator().manual_seed(11)
+    Co, Ci, S = 8, 16, 5
+    slab = torch.randn(S, Co, 9, Ci, generator=g)
+    sd = slab.to(DEV)
+    out = torch.full((Co, Ci, 3, 3), float("nan"), device=DEV)
+    # slab [co][tap][ci] -> weight [co][ci][tap]
+    L.call("vae_reduce_slabs_scatter", L.ptr(sd), S, Co * 9 * Ci, 0, L.ptr(out), L.long4(Co, 9, Ci, 1),
+           L.long4(9 * Ci, 1, 9, 0), None, 0, 0, L.current_stream())
+    ref = slab.sum(0).permute(0, 2, 1).reshape(Co, Ci, 3, 3)
+    assert rel_l2(out.cpu(), ref) <= 1e-6
+    # padding limits: only taps < 7 and channels < 10 are written
+    out2 = torch.zeros(Co, 10, 7, device=DEV)
+    L.call("vae_reduce_slabs_scatter", L.ptr(sd), S, Co * 9 * Ci, 0, L.ptr(out2), L.long4(Co, 9, Ci, 1),
+           L.long4(70, 1, 7, 0), L.long4(Co, 7, 10, 1), 0, 0, L.current_stream())
+    assert rel_l2(out2.cpu(), slab.sum(0)[:, :7, :10].permute(0, 2, 1)) <= 1e-6
+
+    # multi-pack: two jobs in one launch (bf16 pack with a permutation, fp32 permuting copy)
+    w = torch.randn(Co, Ci, 3, 3, generator=g)
+    b = torch.randn(12, generator=g)
+    wd, bd = w.to(DEV), b.to(DEV)
+    wp = torch.zeros(Co, 9, Ci, device=DEV, dtype=torch.bfloat16)
+    bp = torch.zeros(12, device=DEV)
+
+    class Job(ctypes.Structure):
+        _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("dims", ctypes.c_long * 4),
+                    ("strides", ctypes.c_long * 4), ("base", ctypes.c_long), ("f32", ctypes.c_int)]
+    jobs = (Job * 2)()
+    jobs[0] = Job(wd.data_ptr(), wp.data_ptr(), (ctypes.c_long * 4)(Co, Ci, 9, 1), (ctypes.c_long * 4)(9 * Ci, 1, Ci, 0), 0, 0)
+    jobs[1] = Job(bd.data_ptr(), bp.data_ptr(), (ctypes.c_long * 4)(3, 4, 1, 1), (ctypes.c_long * 4)(1, 3, 0, 0), 0, 1)
+    L.call("vae_multi_pack", jobs, 2, L.current_stream())
+    assert torch.equal(wp.float().cpu(), w.permute(0, 2, 3, 1).reshape(Co, 9, Ci).to(torch.bfloat16).float())
+    assert torch.equal(bp.cpu(), b.view(3, 4).t().reshape(-1))
+
+
+@pytest.mark.parametrize("n", [4096 * 997 + 3, 1000])
+def test_adamw_clip_step_matches_oracle(L, n):
+    g = torch.Generator().manual_seed(n)
+    p, grad = torch.randn(n, generator=g), torch.randn(n, generator=g) * (3.0 / n ** 0.5)
+    params, grads = {"w": p.clone()}, {"w": grad.clone()}
+    m, v = {"w": torch.zeros(n)}, {"w": torch.zeros(n)}
+    pd, gd = p.to(DEV), grad.to(DEV)
+    md, vd = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    part = torch.empty(L.call("vae_adamw_grid", n), device=DEV)
+    norm = torch.zeros(1, device=DEV)
+    for step in (1, 2, 3):
+        gn = O.clip_grad_norm(grads, 1.0)
+        O.adamw_step(params, grads, m, v, step, lr=1e-3)
+        L.call("vae_adamw_clip_step", L.ptr(pd), L.ptr(gd), L.ptr(md), L.ptr(vd), n, L.ptr(part), 1.0, 1.0, 1e-3, 0.9, 0.999,
+               1e-8, 0.01, step, L.ptr(norm), L.current_stream())
+        assert abs(norm.item() - gn.item()) <= 1e-5 * gn.item()
+        assert rel_l2(pd.cpu(), params["w"]) <= 1e-6
+        assert rel_l2(md.cpu(), m["w"]) <= 1e-5 and rel_l2(vd.cpu(), v["w"]) <= 1e-5
+        grads["w"] = grad.clone()      # the oracle clipped in place; the kernel leaves grads untouched

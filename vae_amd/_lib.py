@@ -50,13 +50,15 @@ SIGNATURES = {
                               c_ulonglong, c_uint, c_uint, c_uint, P]),
     "vae_head_fwd": (None, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "vae_head_bwd_blocks": (c_int, [c_int, c_int, c_int]),
-    "vae_head_bwd": (None, [P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "vae_head_bwd": (None, [P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "vae_reduce_slabs_scatter": (None, [P, c_int, c_long, c_long, P, P, P, P, c_long, c_int, P]),
+    "vae_multi_pack": (None, [P, c_int, P]),
     "vae_tanh_bwd_rows": (c_int, [c_int]),
     "vae_tanh_bwd": (None, [P, P, P, P, c_int, c_int, P]),
     "vae_nchw_to_nhwc8": (None, [P, P, c_int, c_int, c_int, c_int, P]),
     "vae_adamw_grid": (c_int, [c_long]),
-    "vae_adamw_clip_step": (None, [P, P, P, P, c_long, P, c_float, c_float, c_float, c_float, c_float,
-                                   c_float, c_float, c_int, P, P]),
+    "vae_adamw_clip_step": (None, [P, P, P, P, c_long, P, c_float, c_float, c_double, c_double, c_double,
+                                   c_double, c_double, c_int, P, P]),
     "vae_permute_f32": (None, [P, P, P, P, c_long, P]),
     "vae_cast_bf16": (None, [P, P, c_long, P]),
     "vae_model_param_count": (c_long, [P]),

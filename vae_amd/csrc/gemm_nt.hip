@@ -38,13 +38,30 @@ typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 typedef __attribute__((address_space(3))) short4v* l4ptr_t;
 
-__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* base, int rowb, int k0, int col0, int lane) {
+// Bank swizzle of the row-major [k][channel] LDS tiles.  One transposing read touches, per
+// 32-lane half, 8 rows {b..b+3, b+8..b+11} x 32 contiguous bytes; unswizzled, rows 256 B (or
+// 128 B) apart land on the same banks (8-way / 4-way conflict).  XOR-ing the 16-byte chunk
+// index with an even number derived from the row spreads those 8 rows over 8 distinct 32-byte
+// slots of the 256-byte bank line.  The image is written by global_load_lds (lane-linear), so the
+// same XOR is applied to the SOURCE chunk each lane fetches.
+template <int ROWB>
+__device__ __forceinline__ int tr_swz(int row) {
+    if (ROWB >= 256) return ((row & 3) | (((row >> 3) & 1) << 2)) << 1;
+    return (((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1;
+}
+
+template <int ROWB>
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* base, int k0, int col0, int lane) {
     // lanes 16g..16g+15 fetch k rows k0+8g .. k0+8g+7 of columns col0..col0+15, transposed:
     // lane (l&15) receives column col0+(l&15), elements = 8 consecutive k.
     const int g = lane >> 4, t = lane & 15;
-    const unsigned char* a = base + (k0 + 8 * g + (t >> 2)) * rowb + (col0 + 4 * (t & 3)) * 2;
+    const int row = k0 + 8 * g + (t >> 2);
+    const int off = (col0 + 4 * (t & 3)) * 2;            // byte offset inside the row
+    const int chunk = off >> 4, within = off & 15;
+    const unsigned char* a = base + row * ROWB + (((chunk ^ tr_swz<ROWB>(row)) << 4) | within);
+    const unsigned char* b = base + (row + 4) * ROWB + (((chunk ^ tr_swz<ROWB>(row + 4)) << 4) | within);
     const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((l4ptr_t)(a));
-    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((l4ptr_t)(a + 4 * rowb));
+    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((l4ptr_t)(b));
     typedef __attribute__((ext_vector_type(8))) short short8v;
     const short8v v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_bit_cast(bf16x8, v);
@@ -92,7 +109,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNT p) {
 #pragma unroll
         for (int i = 0; i < P_INSTR; ++i) {
             const int t = wave + 4 * i;
-            const int row = t * (64 / P_CH) + lane / P_CH, chunk = lane % P_CH;
+            const int row = t * (64 / P_CH) + lane / P_CH, chunk = (lane % P_CH) ^ tr_swz<ROWP>(row);
             const int k = k0 + row;
             const bf16_t* src = zero;
             if (k < kend) {
@@ -109,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNT p) {
 #pragma unroll
         for (int i = 0; i < Q_INSTR; ++i) {
             const int t = wave + 4 * i;
-            const int row = t * (64 / Q_CH) + lane / Q_CH, chunk = lane % Q_CH;
+            const int row = t * (64 / Q_CH) + lane / Q_CH, chunk = (lane % Q_CH) ^ tr_swz<ROWQ>(row);
             const int k = k0 + row;
             const bf16_t* src = zero;
             if (k < kend) {
@@ -151,9 +168,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNT p) {
         for (int kk = 0; kk < BK / 32; ++kk) {
             bf16x8 qa[FN], pb[FM];
 #pragma unroll
-            for (int i = 0; i < FN; ++i) qa[i] = tr_frag(qbase, ROWQ, kk * 32, wn * TNw + i * 16, lane);
+            for (int i = 0; i < FN; ++i) qa[i] = tr_frag<ROWQ>(qbase, kk * 32, wn * TNw + i * 16, lane);
 #pragma unroll
-            for (int j = 0; j < FM; ++j) pb[j] = tr_frag(pbase, ROWP, kk * 32, wm * TMw + j * 16, lane);
+            for (int j = 0; j < FM; ++j) pb[j] = tr_frag<ROWP>(pbase, kk * 32, wm * TMw + j * 16, lane);
 #pragma unroll
             for (int i = 0; i < FN; ++i)
 #pragma unroll
@@ -201,6 +218,80 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
         float s = 0.f;
         for (int k = 0; k < nsplit; ++k) s += slab[(long)k * slab_stride + src];
         out[e] = accumulate ? out[e] + s : s;
+    }
+}
+
+// Same fold, but walking the SLAB in its own order (coalesced reads of every split) and
+// scattering the few results: out[map(q)] (+)= sum_s slab[s][q], q over (D0,D1,D2,D3) = the slab's
+// own dims; index tuples with i_d >= lim_d are padding and are skipped.
+struct Limits {
+    int l0, l1, l2, l3;
+};
+__global__ __launch_bounds__(256) void reduce_slabs_scatter_kernel(const float* __restrict__ slab, int nsplit,
+                                                                   long slab_stride, float* __restrict__ out, long n,
+                                                                   IndexMap mp, Limits lim, int accumulate) {
+    // 64 lanes x 16 bytes of consecutive slab elements, 4 split groups per workgroup (n % 4 == 0)
+    __shared__ float4 red[4][64];
+    const int ql = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const long n4 = n >> 2;
+    for (long b = (long)blockIdx.x * 64; b < n4; b += (long)gridDim.x * 64) {
+        const long q4 = b + ql;
+        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+        if (q4 < n4) {
+            const float4* src = (const float4*)slab + q4;
+            int k = sg;
+            for (; k + 4 < nsplit; k += 8) {
+                const float4 u = src[(long)k * (slab_stride >> 2)], w = src[(long)(k + 4) * (slab_stride >> 2)];
+                a0.x += u.x; a0.y += u.y; a0.z += u.z; a0.w += u.w;
+                a1.x += w.x; a1.y += w.y; a1.z += w.z; a1.w += w.w;
+            }
+            if (k < nsplit) {
+                const float4 u = src[(long)k * (slab_stride >> 2)];
+                a0.x += u.x; a0.y += u.y; a0.z += u.z; a0.w += u.w;
+            }
+        }
+        red[sg][ql] = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
+        __syncthreads();
+        // thread (sg, ql) finishes element sg of lane ql's float4
+        if (q4 < n4) {
+            const float* r0 = (const float*)&red[0][ql];
+            const float* r1 = (const float*)&red[1][ql];
+            const float* r2 = (const float*)&red[2][ql];
+            const float* r3 = (const float*)&red[3][ql];
+            const float s = (r0[sg] + r1[sg]) + (r2[sg] + r3[sg]);
+            const long q = (q4 << 2) + sg;
+            const int i3 = (int)(q % mp.d3);
+            long t = q / mp.d3;
+            const int i2 = (int)(t % mp.d2);
+            t /= mp.d2;
+            const int i1 = (int)(t % mp.d1);
+            const long i0 = t / mp.d1;
+            if (i0 < lim.l0 && i1 < lim.l1 && i2 < lim.l2 && i3 < lim.l3) {
+                const long dst = mp.base + i0 * mp.s0 + i1 * mp.s1 + i2 * mp.s2 + i3 * mp.s3;
+                out[dst] = accumulate ? out[dst] + s : s;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Every weight tensor of the model repacked in ONE launch: blockIdx.y selects the job.
+struct PackJob {
+    const float* src;
+    void* dst;
+    long n;
+    IndexMap mp;
+    int f32;     // 1: fp32 permuting copy, 0: bf16 pack
+};
+struct PackJobs {
+    PackJob j[VAE_MAX_PACK_JOBS];
+};
+__global__ __launch_bounds__(256) void multi_pack_kernel(const PackJobs jobs) {
+    const PackJob& jb = jobs.j[blockIdx.y];
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < jb.n; e += (long)gridDim.x * blockDim.x) {
+        const long d = map_index(jb.mp, e);
+        if (jb.f32) ((float*)jb.dst)[d] = jb.src[e];
+        else ((bf16_t*)jb.dst)[d] = f2bf(jb.src[e]);
     }
 }
 
@@ -259,11 +350,12 @@ static int launch_nt(const GemmNT& p, int nsplit, hipStream_t s) {
 using namespace vae;
 
 extern "C" int vae_wgrad_ksplit(int M, int N, int taps, long Ktot) {
-    // aim at ~1024 workgroups, at least 256 k rows each
-    long tiles = (long)((M + 127) / 128) * ((N + 127) / 128) * taps;
-    if (M % 128) tiles = tiles * 1;   // 64-wide tiles: count stays a lower bound
-    long s = (1024 + tiles - 1) / tiles;
-    const long maxs = (Ktot + 255) / 256;
+    // aim at ~512 workgroups (2 per CU) with at least 1024 k rows each: every split costs one
+    // slab of the whole weight tensor in HBM traffic, so small-K layers get few splits
+    const long tm = M % 128 == 0 ? M / 128 : M / 64, tn = N % 128 == 0 ? N / 128 : N / 64;
+    const long tiles = tm * tn * taps;
+    long s = (512 + tiles - 1) / tiles;
+    const long maxs = (Ktot + 1023) / 1024;
     if (s > maxs) s = maxs;
     if (s < 1) s = 1;
     if (s > 256) s = 256;
@@ -358,5 +450,46 @@ extern "C" int vae_cast_bf16(const float* src, void* dst, long n, void* stream) 
     const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
     hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n);
     VAE_LAUNCH_CHECK("cast_bf16_kernel");
+    return 0;
+}
+
+extern "C" int vae_reduce_slabs_scatter(const float* slab, int nsplit, long slab_stride, long slab_base, float* out,
+                                        const long* dims4, const long* strides4, const long* limits4, long base,
+                                        int accumulate, void* stream) {
+    VAE_CHECK(slab && out && nsplit > 0, "vae_reduce_slabs_scatter: bad arguments");
+    IndexMap mp;
+    if (int e = make_map(mp, dims4, strides4, base, "vae_reduce_slabs_scatter")) return e;
+    Limits lim = {(int)dims4[0], (int)dims4[1], (int)dims4[2], (int)dims4[3]};
+    if (limits4) lim = {(int)limits4[0], (int)limits4[1], (int)limits4[2], (int)limits4[3]};
+    const long n = dims4[0] * dims4[1] * dims4[2] * dims4[3];
+    VAE_CHECK(n % 4 == 0 && slab_stride % 4 == 0 && slab_base % 4 == 0 && ((uintptr_t)slab & 15) == 0,
+              "vae_reduce_slabs_scatter: element count, slab stride and base must be multiples of 4 (16-byte rows)");
+    const int grid = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+    ProfScope prof("reduce_slabs_scatter_kernel", 0.0, 4.0 * n * (nsplit + 1), (hipStream_t)stream);
+    hipLaunchKernelGGL(reduce_slabs_scatter_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, slab + slab_base,
+                       nsplit, slab_stride, out, n, mp, lim, accumulate);
+    VAE_LAUNCH_CHECK("reduce_slabs_scatter_kernel");
+    return 0;
+}
+
+// jobs: njobs x {src, dst, n, dims[3] (D1..D3), strides[4], base, f32}; one launch for all of them
+extern "C" int vae_multi_pack(const vae_pack_job* jobs, int njobs, void* stream) {
+    VAE_CHECK(jobs && njobs > 0 && njobs <= VAE_MAX_PACK_JOBS, "vae_multi_pack: njobs=%d out of range (1..%d)", njobs,
+              VAE_MAX_PACK_JOBS);
+    PackJobs pj;
+    double bytes = 0;
+    for (int i = 0; i < njobs; ++i) {
+        VAE_CHECK(jobs[i].src && jobs[i].dst, "vae_multi_pack: job %d has a null pointer", i);
+        const long dims[4] = {jobs[i].dims[0], jobs[i].dims[1], jobs[i].dims[2], jobs[i].dims[3]};
+        if (int e = make_map(pj.j[i].mp, dims, jobs[i].strides, jobs[i].base, "vae_multi_pack")) return e;
+        pj.j[i].src = jobs[i].src;
+        pj.j[i].dst = jobs[i].dst;
+        pj.j[i].n = dims[0] * dims[1] * dims[2] * dims[3];
+        pj.j[i].f32 = jobs[i].f32;
+        bytes += pj.j[i].n * (jobs[i].f32 ? 8.0 : 6.0);
+    }
+    ProfScope prof("multi_pack_kernel", 0.0, bytes, (hipStream_t)stream);
+    hipLaunchKernelGGL(multi_pack_kernel, dim3(64, njobs), dim3(256), 0, (hipStream_t)stream, pj);
+    VAE_LAUNCH_CHECK("multi_pack_kernel");
     return 0;
 }

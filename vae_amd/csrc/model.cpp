@@ -165,7 +165,7 @@ void make_ws_layout(const Dims& d, WsLayout* w) {
     w->coef = put(11L * 4 * 256 * 4);
     const long stat = (long)rows_blocks(npix) * 64;       // widest: first block (64 ch at full res) == up1 (256 cols at half res)
     const long stat2 = (long)rows_blocks(npix / 4) * 256;
-    const long statn = stat > stat2 ? stat : stat2;
+    const long statn = (stat > stat2 ? stat : stat2) + VAE_STAT_SCRATCH_ROWS * 256L;   // + the fold's scratch rows
     w->stat_sum = put(statn * 4); w->stat_sq = put(statn * 4);
     w->zb = put((long)d.N * d.L * 2);
     w->klp = put(2048 * 4);
@@ -231,20 +231,25 @@ int make_ctx(Ctx* c, const vae_model_cfg* cfg, const char* who) {
     return 0;
 }
 
-int pack4(const float* src, void* dst, long d0, long d1, long d2, long d3, long s0, long s1, long s2, long s3, long base,
-          void* stream) {
+// pack / permute jobs collected on the host stack and issued as ONE launch
+struct JobList {
+    vae_pack_job j[VAE_MAX_PACK_JOBS];
+    int n = 0;
+    void add(const float* src, void* dst, int f32, long d0, long d1, long d2, long d3, long s0, long s1, long s2, long s3,
+             long base) {
+        vae_pack_job& q = j[n++];
+        q.src = src; q.dst = dst; q.f32 = f32; q.base = base;
+        q.dims[0] = d0; q.dims[1] = d1; q.dims[2] = d2; q.dims[3] = d3;
+        q.strides[0] = s0; q.strides[1] = s1; q.strides[2] = s2; q.strides[3] = s3;
+    }
+};
+// fold `ns` slabs: q walks the slab's own dims (d0..d3, row-major), results land at
+// out[i0*s0 + i1*s1 + i2*s2 + i3*s3]; (l0..l3) bound the valid (non-padding) index range
+int reduce4(const float* slab, int ns, long stride, long slab_base, float* out, long d0, long d1, long d2, long d3, long s0,
+            long s1, long s2, long s3, void* stream, long l1 = -1, long l2 = -1) {
     const long dims[4] = {d0, d1, d2, d3}, st[4] = {s0, s1, s2, s3};
-    return vae_pack_bf16(src, dst, dims, st, base, stream);
-}
-int perm4(const float* src, float* dst, long d0, long d1, long d2, long d3, long s0, long s1, long s2, long s3, long base,
-          void* stream) {
-    const long dims[4] = {d0, d1, d2, d3}, st[4] = {s0, s1, s2, s3};
-    return vae_permute_f32(src, dst, dims, st, base, stream);
-}
-int reduce4(const float* slab, int ns, long stride, float* out, long d0, long d1, long d2, long d3, long s0, long s1,
-            long s2, long s3, long base, void* stream) {
-    const long dims[4] = {d0, d1, d2, d3}, st[4] = {s0, s1, s2, s3};
-    return vae_reduce_slabs(slab, ns, stride, out, dims, st, base, 0, stream);
+    const long lim[4] = {d0, l1 < 0 ? d1 : l1, l2 < 0 ? d2 : l2, d3};
+    return vae_reduce_slabs_scatter(slab, ns, stride, slab_base, out, dims, st, lim, 0, 0, stream);
 }
 
 // BatchNorm finalize for BN `bi` from the GEMM epilogue partials (train) or running stats (eval)
@@ -252,7 +257,7 @@ int bn_finalize(const Ctx& c, int bi, int g_idx, int rows, int fold, double coun
     const int C = c.pl.bn_c[bi];
     float* rm = c.bn + c.pl.bn_off[bi];
     const int train = c.cfg->train;
-    return vae_bn_finalize((const float*)c.at(c.ws.stat_sum), (const float*)c.at(c.ws.stat_sq), rows, C, fold, count,
+    return vae_bn_finalize((float*)c.at(c.ws.stat_sum), (float*)c.at(c.ws.stat_sq), rows, C, fold, count,
                            c.P(g_idx), c.P(g_idx + 1), rm, rm + C, 0.1f, 1e-5f, train ? 0 : 1, c.coef(bi, 0),
                            c.coef(bi, 1), c.coef(bi, 2), c.coef(bi, 3), c.stream);
 }
@@ -293,31 +298,31 @@ extern "C" int vae_model_pack_weights(const vae_model_cfg* cfg, const float* par
     CHECK(params && wpack, "vae_model_pack_weights: null pointer");
     c.params = (float*)params; c.wpack = (char*)wpack; c.stream = stream;
     const Dims& d = c.d;
-    hipStream_t s = (hipStream_t)stream;
-    CHECK(hipMemsetAsync(c.pk_at(c.pk.c1a), 0, 64 * 128 * 2, s) == hipSuccess, "vae_model_pack_weights: memset failed");
-    TRY(pack4(c.P(0), c.pk_at(c.pk.c1a), 64, d.Cin, 9, 1, 128, 1, 8, 0, 0, stream));
+    JobList jl;
+    // first conv: [64][16 taps][8 ch]; taps >= 9 / channels >= Cin stay zero (wpack is zero-filled once by the caller)
+    jl.add(c.P(0), c.pk_at(c.pk.c1a), 0, 64, d.Cin, 9, 1, 128, 1, 8, 0, 0);
     for (int i = 0; i < 7; ++i) {
         const long Ci = CONV_CI[i], Co = CONV_CO[i];
-        TRY(pack4(c.P(CONV_PARAM[i]), c.pk_at(c.pk.conv_f[i]), Co, Ci, 9, 1, 9 * Ci, 1, Ci, 0, 0, stream));
-        TRY(pack4(c.P(CONV_PARAM[i]), c.pk_at(c.pk.conv_d[i]), Co, Ci, 9, 1, 1, 9 * Co, -Co, 0, 8 * Co, stream));
+        jl.add(c.P(CONV_PARAM[i]), c.pk_at(c.pk.conv_f[i]), 0, Co, Ci, 9, 1, 9 * Ci, 1, Ci, 0, 0);
+        jl.add(c.P(CONV_PARAM[i]), c.pk_at(c.pk.conv_d[i]), 0, Co, Ci, 9, 1, 1, 9 * Co, -Co, 0, 8 * Co);
     }
     const long L = d.L, F = d.F, hw = d.hw;
     for (int t = 0; t < 2; ++t) {   // fc_mu, fc_logvar -> one [2L][F] operand, columns in NHWC order
         const float* src = c.P(t ? P_FC_LV_W : P_FC_MU_W);
-        TRY(pack4(src, c.pk_at(c.pk.fc_f), L, 256, hw, 1, F, 1, 256, 0, t * L * F, stream));
-        TRY(pack4(src, c.pk_at(c.pk.fc_d), L, 256, hw, 1, 1, 2 * L, 256 * 2 * L, 0, t * L, stream));
-        TRY(perm4(c.P(t ? P_FC_LV_B : P_FC_MU_B), (float*)c.pk_at(c.pk.bcat), L, 1, 1, 1, 1, 0, 0, 0, t * L, stream));
+        jl.add(src, c.pk_at(c.pk.fc_f), 0, L, 256, hw, 1, F, 1, 256, 0, t * L * F);
+        jl.add(src, c.pk_at(c.pk.fc_d), 0, L, 256, hw, 1, 1, 2 * L, 256 * 2 * L, 0, t * L);
+        jl.add(c.P(t ? P_FC_LV_B : P_FC_MU_B), c.pk_at(c.pk.bcat), 1, L, 1, 1, 1, 1, 0, 0, 0, t * L);
     }
-    TRY(pack4(c.P(P_FC_UP_W), c.pk_at(c.pk.up_f), 256, hw, L, 1, L, 256 * L, 1, 0, 0, stream));
-    TRY(pack4(c.P(P_FC_UP_W), c.pk_at(c.pk.up_d), 256, hw, L, 1, 1, 256, F, 0, 0, stream));
-    TRY(perm4(c.P(P_FC_UP_B), (float*)c.pk_at(c.pk.bup), 256, hw, 1, 1, 1, 256, 0, 0, 0, stream));
+    jl.add(c.P(P_FC_UP_W), c.pk_at(c.pk.up_f), 0, 256, hw, L, 1, L, 256 * L, 1, 0, 0);
+    jl.add(c.P(P_FC_UP_W), c.pk_at(c.pk.up_d), 0, 256, hw, L, 1, 1, 256, F, 0, 0);
+    jl.add(c.P(P_FC_UP_B), c.pk_at(c.pk.bup), 1, 256, hw, 1, 1, 1, 256, 0, 0, 0);
     for (int u = 0; u < 3; ++u) {
         const long Ci = DEC_CI[u], Co = DEC_CO[u];
         const float* src = c.P(P_UP3_W + 4 * u);
-        TRY(pack4(src, c.pk_at(c.pk.ct_f[u]), Ci, Co, 4, 1, 1, Ci, Co * Ci, 0, 0, stream));
-        TRY(pack4(src, c.pk_at(c.pk.ct_d[u]), Ci, Co, 4, 1, 4 * Co, 1, Co, 0, 0, stream));
+        jl.add(src, c.pk_at(c.pk.ct_f[u]), 0, Ci, Co, 4, 1, 1, Ci, Co * Ci, 0, 0);
+        jl.add(src, c.pk_at(c.pk.ct_d[u]), 0, Ci, Co, 4, 1, 4 * Co, 1, Co, 0, 0);
     }
-    return 0;
+    return vae_multi_pack(jl.j, jl.n, stream);
 }
 
 // Decoder forward from z (bf16 [N][L] in the workspace) to recon; shared by forward and decode.
@@ -444,14 +449,10 @@ static int backward_decoder(const Ctx& c, const float* d_recon, const float* rec
     hipStream_t s = (hipStream_t)c.stream;
     int ns = 1;
     // 1x1 head + bn1
-    float* hs = (float*)c.at(w.headsums);
+    // [d gamma1 | d beta1] and [d head.weight | d head.bias] are adjacent in the flat layout
     TRY(vae_head_bwd(d_recon, recon, c.at(w.yd[2]), c.coef(10, 0), c.coef(10, 1), c.coef(10, 2), c.coef(10, 3),
-                     c.P(P_HEAD_W), (float*)c.at(w.headpart), hs, c.at(w.g0), d.N, d.S, d.S, d.Cout, c.stream));
-    CHECK(hipMemcpyAsync(c.G(P_BN1_G), hs, 64 * 4, hipMemcpyDeviceToDevice, s) == hipSuccess &&
-              hipMemcpyAsync(c.G(P_BN1_B), hs + 64, 64 * 4, hipMemcpyDeviceToDevice, s) == hipSuccess &&
-              hipMemcpyAsync(c.G(P_HEAD_W), hs + 128, (long)d.Cout * 64 * 4, hipMemcpyDeviceToDevice, s) == hipSuccess &&
-              hipMemcpyAsync(c.G(P_HEAD_B), hs + 128 + d.Cout * 64, d.Cout * 4, hipMemcpyDeviceToDevice, s) == hipSuccess,
-          "vae_model_backward: gradient copy failed");
+                     c.P(P_HEAD_W), (float*)c.at(w.headpart), c.G(P_BN1_G), c.G(P_HEAD_W), c.at(w.g0), d.N, d.S, d.S,
+                     d.Cout, c.stream));
     // up1, up2, up3 (u = 2, 1, 0): dy in g0 -> input grad in g1 -> bn backward -> g0 ...
     for (int u = 2; u >= 0; --u) {
         const int hh = s8 << u;    // input grid
@@ -459,8 +460,9 @@ static int backward_decoder(const Ctx& c, const float* d_recon, const float* rec
         const int Ci = DEC_CI[u], Co = DEC_CO[u];
         const void* xin = u == 0 ? c.at(w.h) : c.at(w.ad[u - 1]);
         TRY(wgrad_to(c, c.at(w.g0), xin, Co, Ci, Min, Co, Ci, VAE_WGRAD_CONVT, hh, hh, 4, &ns));
-        TRY(reduce4((float*)c.at(w.slab), ns, 4L * Co * Ci, c.G(P_UP3_W + 4 * u), Ci, Co, 4, 1, 1, 4 * Ci, Ci, 0, 0, c.stream));
-        TRY(zero_grad(c, P_UP3_B + 4 * u));   // bias in front of a train-mode BatchNorm: gradient is exactly 0
+        // slab [co][tap][ci] -> ConvTranspose2d weight [ci][co][tap]
+        TRY(reduce4((float*)c.at(w.slab), ns, 4L * Co * Ci, 0, c.G(P_UP3_W + 4 * u), Co, 4, Ci, 1, 4, 1, 4L * Co, 0, c.stream));
+        // (the bias in front of a train-mode BatchNorm has an identically zero gradient: its slot is left as it is)
         TRY(vae_convt2x2_dgrad_gemm(c.at(w.g0), c.pk_at(c.pk.ct_d[u]), c.at(w.g1), d.N, hh, hh, Ci, Co, c.stream));
         if (u > 0) {
             const int bi = 8 + (u - 1);
@@ -473,9 +475,11 @@ static int backward_decoder(const Ctx& c, const float* d_recon, const float* rec
     const int nr = vae_tanh_bwd_rows(d.N);
     TRY(vae_tanh_bwd(c.at(w.g1), c.at(w.h), c.at(w.dpre), (float*)c.at(w.colp), d.N, d.F, c.stream));
     // fc_up.bias grad: column sums, NHWC order -> parameter order via a permuting reduce
-    TRY(reduce4((float*)c.at(w.colp), nr, d.F, c.G(P_FC_UP_B), 256, d.hw, 1, 1, 1, 256, 0, 0, 0, c.stream));
+    TRY(reduce4((float*)c.at(w.colp), nr, d.F, 0, c.G(P_FC_UP_B), 1, d.hw, 256, 1, 0, 1, d.hw, 0, c.stream));
     TRY(wgrad_to(c, c.at(w.dpre), c.at(w.zb), d.F, d.L, d.N, d.F, d.L, VAE_WGRAD_PLAIN, 1, 1, 1, &ns));
-    TRY(reduce4((float*)c.at(w.slab), ns, (long)d.F * d.L, c.G(P_FC_UP_W), 256, d.hw, d.L, 1, d.L, 256L * d.L, 1, 0, 0, c.stream));
+    // slab [(p, c)][l] -> fc_up.weight [(c, p)][l]
+    TRY(reduce4((float*)c.at(w.slab), ns, (long)d.F * d.L, 0, c.G(P_FC_UP_W), d.hw, 256, d.L, 1, d.L, (long)d.hw * d.L, 1, 0,
+                c.stream));
     TRY(vae_linear_gemm(c.at(w.dpre), c.pk_at(c.pk.up_d), nullptr, c.at(w.dz), nullptr, nullptr, nullptr, d.N, d.L, d.F,
                         VAE_EPI_F32, c.stream));
     TRY(vae_reparam_kl_bwd((const float*)c.at(w.dz), mu, logvar, eps_in, dmu_ext, dlv_ext, kl_scale, (float*)c.at(w.dmu),
@@ -485,8 +489,9 @@ static int backward_decoder(const Ctx& c, const float* d_recon, const float* rec
     TRY(vae_sum_partials((const float*)c.at(w.dlv), d.N, d.L, c.G(P_FC_LV_B), 1.0f, c.stream));
     TRY(wgrad_to(c, c.at(w.dcat), c.at(w.ob[3]), 2 * d.L, d.F, d.N, 2 * d.L, d.F, VAE_WGRAD_PLAIN, 1, 1, 1, &ns));
     for (int t = 0; t < 2; ++t)
-        TRY(reduce4((float*)c.at(w.slab), ns, 2L * d.L * d.F, c.G(t ? P_FC_LV_W : P_FC_MU_W), d.L, 256, d.hw, 1, d.F, 1, 256, 0,
-                    (long)t * d.L * d.F, c.stream));
+        // slab rows [t*L, (t+1)*L) x columns (p, c) -> fc weight [l][(c, p)]
+        TRY(reduce4((float*)c.at(w.slab), ns, 2L * d.L * d.F, (long)t * d.L * d.F, c.G(t ? P_FC_LV_W : P_FC_MU_W), d.L, d.hw,
+                    256, 1, d.F, 1, d.hw, 0, c.stream));
     // d(encoder output) [N][F] bf16 -> g0
     return vae_linear_gemm(c.at(w.dcat), c.pk_at(c.pk.fc_d), nullptr, c.at(w.g0), nullptr, nullptr, nullptr, d.N, d.F,
                            2 * d.L, VAE_EPI_BF16, c.stream);
@@ -505,21 +510,21 @@ static int backward_block(const Ctx& c, int b, const void* const* masks) {
                        c.coef(2 * b + 1, 3), (float*)c.at(w.bnpart), c.G(8 * b + 6), c.at(w.g1), d.N, H, H, C, b < 3, p,
                        masks ? masks[b] : nullptr, c.cfg->seed, c.cfg->step, VAE_STREAM_DROPOUT0 + b, c.cfg->rank, c.stream));
     TRY(wgrad_to(c, c.at(w.g1), c.at(w.aa[b]), C, C, M, C, C, VAE_WGRAD_CONV3, H, H, 9, &ns));
-    TRY(reduce4((float*)c.at(w.slab), ns, 9L * C * C, c.G(8 * b + 4), C, C, 9, 1, 9 * C, 1, C, 0, 0, c.stream));
-    TRY(zero_grad(c, 8 * b + 5));
+    // slab [co][tap][ci] -> Conv2d weight [co][ci][tap]
+    TRY(reduce4((float*)c.at(w.slab), ns, 9L * C * C, 0, c.G(8 * b + 4), C, 9, C, 1, 9L * C, 1, 9, 0, c.stream));
     TRY(vae_conv3x3_gemm(c.at(w.g1), c.pk_at(c.pk.conv_d[2 * b]), nullptr, c.at(w.g0), nullptr, nullptr, d.N, H, H, C, C,
                          c.stream));
     // first conv + BN + ReLU
     TRY(vae_bn_act_bwd(c.at(w.g0), c.at(w.ya[b]), c.coef(2 * b, 0), c.coef(2 * b, 1), c.coef(2 * b, 2), c.coef(2 * b, 3),
                        (float*)c.at(w.bnpart), c.G(8 * b + 2), c.at(w.g1), d.N, H, H, C, 0, 0.0, nullptr, 0, 0, 0, 0, c.stream));
-    TRY(zero_grad(c, 8 * b + 1));
     if (b == 0) {
         TRY(wgrad_to(c, c.at(w.g1), c.at(w.x8), C, 64, M, C, 8, VAE_WGRAD_CONV3_C8, H, H, 2, &ns));
-        return reduce4((float*)c.at(w.slab), ns, 64L * 128, c.G(0), 64, d.Cin, 9, 1, 128, 1, 8, 0, 0, c.stream);
+        // slab [co][16 taps][8 ch] (taps >= 9, channels >= Cin are padding) -> weight [co][ci][tap]
+        return reduce4((float*)c.at(w.slab), ns, 64L * 128, 0, c.G(0), 64, 16, 8, 1, 9L * d.Cin, 1, 9, 0, c.stream, 9, d.Cin);
     }
     const int Ci = ENC_C[b - 1];
     TRY(wgrad_to(c, c.at(w.g1), c.at(w.ob[b - 1]), C, Ci, M, C, Ci, VAE_WGRAD_CONV3, H, H, 9, &ns));
-    TRY(reduce4((float*)c.at(w.slab), ns, 9L * C * Ci, c.G(8 * b), C, Ci, 9, 1, 9 * Ci, 1, Ci, 0, 0, c.stream));
+    TRY(reduce4((float*)c.at(w.slab), ns, 9L * C * Ci, 0, c.G(8 * b), C, 9, Ci, 1, 9L * Ci, 1, 9, 0, c.stream));
     return vae_conv3x3_gemm(c.at(w.g1), c.pk_at(c.pk.conv_d[2 * b - 1]), nullptr, c.at(w.g0), nullptr, nullptr, d.N, H, H, C,
                             Ci, c.stream);
 }

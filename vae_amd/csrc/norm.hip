@@ -125,15 +125,38 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(
     }
 }
 
+// Stage 1 of the statistics fold when there are many partial rows (one CU cannot stream MBs of
+// partials fast enough): grid = (ceil(ncols/64), 32) workgroups each sum rows s, s+32, s+64, ...
+// of BOTH arrays into scratch row `rows + s` (the 32 rows past the partials).
+__global__ __launch_bounds__(256) void stats_stage1_kernel(float* __restrict__ psum, float* __restrict__ psq, int rows,
+                                                           int ncols) {
+    __shared__ float red[2][4][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    float s = 0.f, q = 0.f;
+    if (c < ncols)
+        for (int r = blockIdx.y + 32 * rg; r < rows; r += 128) {
+            s += psum[(long)r * ncols + c];
+            q += psq[(long)r * ncols + c];
+        }
+    red[0][rg][cl] = s;
+    red[1][rg][cl] = q;
+    __syncthreads();
+    if (rg == 0 && c < ncols) {
+        psum[(long)(rows + blockIdx.y) * ncols + c] = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+        psq[(long)(rows + blockIdx.y) * ncols + c] = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
+    }
+}
+
 // out[j] = sum_r partial[r][j]; grid = ceil(ncols/64), block = 1024
 __global__ __launch_bounds__(1024) void sum_partials_kernel(const float* __restrict__ partial, int rows, int ncols,
-                                                            float* __restrict__ out, float mul) {
+                                                            int ld, float* __restrict__ out, float mul) {
     __shared__ double red[16][64];
     const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
     double s = 0.0;
     if (c < ncols)
-        for (int r = rg; r < rows; r += 16) s += (double)partial[(long)r * ncols + c];
+        for (int r = rg; r < rows; r += 16) s += (double)partial[(long)r * ld + c];
     red[rg][cl] = s;
     __syncthreads();
     if (rg == 0 && c < ncols) {
@@ -499,7 +522,7 @@ static int elem_grid(long items) {
 
 using namespace vae;
 
-extern "C" int vae_bn_finalize(const float* stat_sum, const float* stat_sq, int rows, int C, int fold, double count,
+extern "C" int vae_bn_finalize(float* stat_sum, float* stat_sq, int rows, int C, int fold, double count,
                                const float* gamma, const float* beta, float* running_mean, float* running_var,
                                float momentum, float eps, int use_running, float* scale, float* shift, float* mean,
                                float* rstd, void* stream) {
@@ -507,6 +530,16 @@ extern "C" int vae_bn_finalize(const float* stat_sum, const float* stat_sq, int 
     VAE_CHECK(use_running ? (running_mean && running_var) : (stat_sum && stat_sq && rows > 0 && count > 0),
               "vae_bn_finalize: missing statistics input");
     VAE_CHECK(C > 0 && fold > 0, "vae_bn_finalize: bad C=%d fold=%d", C, fold);
+    if (!use_running && rows > VAE_STAT_SCRATCH_ROWS * 2) {
+        // many partial rows: fold them to 32 scratch rows with the whole chip first
+        const int ncols = fold * C;
+        hipLaunchKernelGGL(stats_stage1_kernel, dim3((ncols + 63) / 64, VAE_STAT_SCRATCH_ROWS), dim3(256), 0,
+                           (hipStream_t)stream, stat_sum, stat_sq, rows, ncols);
+        VAE_LAUNCH_CHECK("stats_stage1_kernel");
+        stat_sum += (long)rows * ncols;
+        stat_sq += (long)rows * ncols;
+        rows = VAE_STAT_SCRATCH_ROWS;
+    }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, stat_sum, stat_sq,
                        rows, C, fold, count, gamma, beta, running_mean, running_var, momentum, eps, use_running, scale,
                        shift, mean, rstd);
@@ -517,7 +550,7 @@ extern "C" int vae_bn_finalize(const float* stat_sum, const float* stat_sq, int 
 extern "C" int vae_sum_partials(const float* partial, int rows, int ncols, float* out, float mul, void* stream) {
     VAE_CHECK(partial && out && rows > 0 && ncols > 0, "vae_sum_partials: bad arguments");
     hipLaunchKernelGGL(sum_partials_kernel, dim3((ncols + 63) / 64), dim3(1024), 0, (hipStream_t)stream, partial, rows,
-                       ncols, out, mul);
+                       ncols, ncols, out, mul);
     VAE_LAUNCH_CHECK("sum_partials_kernel");
     return 0;
 }
@@ -544,7 +577,7 @@ extern "C" int vae_bn_act_bwd_blocks(int n_img, int H, int W, int C, int pool) {
     const long items = (long)n_img * H * W / (pool ? 4 : 1) * (C / 8);
     long b = (items + 255) / 256;
     if (b < 1) b = 1;
-    if (b > 1024) b = 1024;
+    if (b > 512) b = 512;
     return (int)b;
 }
 
@@ -568,7 +601,7 @@ extern "C" int vae_bn_act_bwd(const void* gin, const void* y, const float* scale
     if (pool) hipLaunchKernelGGL((bn_act_bwd_kernel<true, 0>), dim3(nb), dim3(256), 0, s, gi, yy, scale, shift, mean, rstd, sums, inv_count, partial, (bf16_t*)dy, g, d);
     else hipLaunchKernelGGL((bn_act_bwd_kernel<false, 0>), dim3(nb), dim3(256), 0, s, gi, yy, scale, shift, mean, rstd, sums, inv_count, partial, (bf16_t*)dy, g, d);
     VAE_LAUNCH_CHECK("bn_act_bwd_kernel<0>");
-    hipLaunchKernelGGL(sum_partials_kernel, dim3((2 * C + 63) / 64), dim3(1024), 0, s, partial, nb, 2 * C, sums, 1.0f);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((2 * C + 63) / 64), dim3(1024), 0, s, partial, nb, 2 * C, 2 * C, sums, 1.0f);
     VAE_LAUNCH_CHECK("sum_partials_kernel");
     const int nb2 = elem_grid((long)n_img * H * W / (pool ? 4 : 1) * (C / 8));
     if (pool) hipLaunchKernelGGL((bn_act_bwd_kernel<true, 1>), dim3(nb2), dim3(256), 0, s, gi, yy, scale, shift, mean, rstd, sums, inv_count, partial, (bf16_t*)dy, g, d);
@@ -596,14 +629,14 @@ extern "C" int vae_head_fwd(const void* y, const float* scale, const float* shif
 extern "C" int vae_head_bwd_blocks(int n_img, int H, int W) {
     long b = ((long)n_img * H * W + 31) / 32;
     if (b < 1) b = 1;
-    if (b > 1024) b = 1024;
+    if (b > 512) b = 512;
     return (int)b;
 }
 
 extern "C" int vae_head_bwd(const float* drecon, const float* recon, const void* y, const float* scale,
                             const float* shift, const float* mean, const float* rstd, const float* w, float* partial,
-                            float* sums, void* dy, int n_img, int H, int W, int Cout, void* stream) {
-    VAE_CHECK(drecon && recon && y && scale && shift && mean && rstd && w && partial && sums && dy, "vae_head_bwd: null pointer");
+                            float* sums, float* sums_head, void* dy, int n_img, int H, int W, int Cout, void* stream) {
+    VAE_CHECK(drecon && recon && y && scale && shift && mean && rstd && w && partial && sums && sums_head && dy, "vae_head_bwd: null pointer");
     VAE_CHECK(n_img > 0 && H > 0 && W > 0, "vae_head_bwd: bad geometry");
     VAE_CHECK(Cout >= 1 && Cout <= 4, "vae_head_bwd: out_channels=%d not supported (1..4)", Cout);
     const long npix = (long)n_img * H * W;
@@ -616,7 +649,10 @@ extern "C" int vae_head_bwd(const float* drecon, const float* recon, const void*
 #define GO(CO, PASS, NB) hipLaunchKernelGGL((head_bwd_kernel<CO, PASS>), dim3(NB), dim3(256), 0, s, drecon, recon, yy, scale, shift, mean, rstd, w, sums, inv_count, partial, (bf16_t*)dy, npix, H * W)
     switch (Cout) { case 1: GO(1, 0, nb); break; case 2: GO(2, 0, nb); break; case 3: GO(3, 0, nb); break; default: GO(4, 0, nb); }
     VAE_LAUNCH_CHECK("head_bwd_kernel<0>");
-    hipLaunchKernelGGL(sum_partials_kernel, dim3((ncols + 63) / 64), dim3(1024), 0, s, partial, nb, ncols, sums, 1.0f);
+    // [d gamma | d beta] -> sums (also the coefficients of pass 1); [dW | db] -> sums_head
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(2), dim3(1024), 0, s, partial, nb, 128, ncols, sums, 1.0f);
+    const int nh = Cout * 64 + Cout;
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((nh + 63) / 64), dim3(1024), 0, s, partial + 128, nb, nh, ncols, sums_head, 1.0f);
     VAE_LAUNCH_CHECK("sum_partials_kernel");
     const int nb2 = (int)((npix + 31) / 32 > 2048 ? 2048 : (npix + 31) / 32);
     switch (Cout) { case 1: GO(1, 1, nb2); break; case 2: GO(2, 1, nb2); break; case 3: GO(3, 1, nb2); break; default: GO(4, 1, nb2); }

@@ -30,7 +30,8 @@ __global__ __launch_bounds__(256) void adamw_clip_kernel(float* __restrict__ p, 
                                                          float* __restrict__ m, float* __restrict__ v, long n,
                                                          const float* __restrict__ partial, int npartial, float grad_mul,
                                                          float max_norm, float lr, float b1, float b2, float eps,
-                                                         float wd, float bc1, float bc2_sqrt, float* __restrict__ norm_out) {
+                                                         float wd, float bc1, float bc2_sqrt, float omb1, float omb2,
+                                                         float* __restrict__ norm_out) {
     __shared__ double red[4];
     __shared__ float coef_s;
     double a = 0.0;
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(256) void adamw_clip_kernel(float* __restrict__ p, 
     }
     __syncthreads();
     const float coef = coef_s;
-    const float step = lr / bc1, decay = 1.f - lr * wd;
+    const float step = lr, decay = wd;   // the host passes lr / bias_correction1 and 1 - lr * weight_decay
     const long n4 = n >> 2;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         float4 P = ((float4*)p)[i], M = ((float4*)m)[i], V = ((float4*)v)[i];
@@ -57,8 +58,8 @@ __global__ __launch_bounds__(256) void adamw_clip_kernel(float* __restrict__ p, 
         for (int k = 0; k < 4; ++k) {
             const float gk = gg[k] * coef;
             pp[k] *= decay;
-            mm[k] = b1 * mm[k] + (1.f - b1) * gk;
-            vv[k] = b2 * vv[k] + (1.f - b2) * gk * gk;
+            mm[k] = b1 * mm[k] + omb1 * gk;
+            vv[k] = b2 * vv[k] + omb2 * gk * gk;
             pp[k] -= step * mm[k] / (sqrtf(vv[k]) / bc2_sqrt + eps);
         }
         ((float4*)p)[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(256) void adamw_clip_kernel(float* __restrict__ p, 
         for (long i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) {
             const float gk = g[i] * coef;
             float pk = p[i] * decay;
-            const float mk = b1 * m[i] + (1.f - b1) * gk, vk = b2 * v[i] + (1.f - b2) * gk * gk;
+            const float mk = b1 * m[i] + omb1 * gk, vk = b2 * v[i] + omb2 * gk * gk;
             pk -= step * mk / (sqrtf(vk) / bc2_sqrt + eps);
             p[i] = pk; m[i] = mk; v[i] = vk;
         }
@@ -87,16 +88,17 @@ extern "C" int vae_adamw_grid(long n) {
 }
 
 extern "C" int vae_adamw_clip_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n,
-                                   float* partial, float grad_mul, float max_norm, float lr, float beta1, float beta2,
-                                   float eps, float weight_decay, int step, float* grad_norm_out, void* stream) {
+                                   float* partial, float grad_mul, float max_norm, double lr, double beta1, double beta2,
+                                   double eps, double weight_decay, int step, float* grad_norm_out, void* stream) {
     VAE_CHECK(params && grads && exp_avg && exp_avg_sq && partial, "vae_adamw_clip_step: null pointer");
     VAE_CHECK(n > 0 && step >= 1, "vae_adamw_clip_step: n=%ld, step=%d must be positive", n, step);
     VAE_CHECK((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0,
               "vae_adamw_clip_step: buffers must be 16-byte aligned");
     const int grid = vae_adamw_grid(n);
     hipStream_t s = (hipStream_t)stream;
-    const float bc1 = 1.f - powf(beta1, (float)step);
-    const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+    // hyper-parameter arithmetic in double, as torch does on the host, then rounded once
+    const float bc1 = (float)(1.0 - pow(beta1, (double)step));
+    const float bc2s = (float)sqrt(1.0 - pow(beta2, (double)step));
     {
         ProfScope prof("sumsq_kernel", 0.0, 4.0 * n, s);
         hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, s, grads, n, partial);
@@ -105,7 +107,9 @@ extern "C" int vae_adamw_clip_step(float* params, const float* grads, float* exp
     {
         ProfScope prof("adamw_clip_kernel", 0.0, 28.0 * n, s);
         hipLaunchKernelGGL(adamw_clip_kernel, dim3(grid), dim3(256), 0, s, params, grads, exp_avg, exp_avg_sq, n, partial,
-                           grid, grad_mul, max_norm, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_norm_out);
+                           grid, grad_mul, max_norm, (float)(lr / (1.0 - pow(beta1, (double)step))), (float)beta1,
+                           (float)beta2, (float)eps, (float)(1.0 - lr * weight_decay), bc1, bc2s, (float)(1.0 - beta1),
+                           (float)(1.0 - beta2), grad_norm_out);
     }
     VAE_LAUNCH_CHECK("adamw_clip_kernel");
     return 0;

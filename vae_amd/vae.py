@@ -164,7 +164,8 @@ class VAEConv(nn.Module):
                 bn.running_mean, bn.running_var, bn.num_batches_tracked = rm, rv, nbt[i]
                 o += 2 * C
         self.flat_params, self.flat_grads, self._bn_stats, self._nbt = flat, grads, stats, nbt
-        self._wpack = torch.empty(lib.vae_model_wpack_bytes(ctypes.byref(cfg)), dtype=torch.uint8, device=device)
+        # zero-filled once: the padding of the packed first-conv operand is never rewritten
+        self._wpack = torch.zeros(lib.vae_model_wpack_bytes(ctypes.byref(cfg)), dtype=torch.uint8, device=device)
         self._packed_version = -1
         self._ws_pool = {}
         self._last = None
@@ -364,8 +365,9 @@ class _VAEConvFunction(torch.autograd.Function):
         d_recon = d_recon.contiguous()
         d_mu = None if d_mu is None else d_mu.contiguous()
         d_logvar = None if d_logvar is None else d_logvar.contiguous()
-        # fresh buffer: autograd may keep (or accumulate into) the tensors returned here
-        out = torch.empty_like(model.flat_grads)
+        # fresh buffer: autograd may keep (or accumulate into) the tensors returned here.  Zeroed:
+        # the backward leaves the identically-zero gradients (biases in front of a BatchNorm) untouched
+        out = torch.zeros_like(model.flat_grads)
         model.backward_raw(state, d_recon, d_mu, d_logvar, 0.0, -1, out)
         model._release_workspace(state["batch"], state["ws"])
         ctx.state = None
