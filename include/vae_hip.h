@@ -85,8 +85,11 @@ int vae_philox_fill(void* out, long n, int mode, double p_drop, unsigned long lo
 unsigned vae_dropout_threshold(double p_drop);
 
 /* ---- implicit-GEMM layers (bf16 MFMA, fp32 accumulate) ---------------------------------- */
-/* rows of the GEMM M dimension per workgroup: stat_sum / stat_sq hold ceil(M/rows) x N floats */
+/* Per-workgroup statistics: a GEMM over M rows and N columns leaves vae_gemm_stat_rows(M, N)
+ * partial rows of N floats in stat_sum / stat_sq (one per workgroup row; the tile height is
+ * 128 or, for small problems, 64 = vae_gemm_rows_per_block(), the bound to size buffers with). */
 int vae_gemm_rows_per_block(void);
+int vae_gemm_stat_rows(long M, int N);
 /* nn.Conv2d(Cin, Cout, 3, padding=1) forward, vae/models/vae.py:129,133 -- and, with the
  * flipped/transposed weight pack, its dgrad.  x [n,H,W,Cin], w_packed [Cout][9][Cin],
  * y [n,H,W,Cout].  stat_* (optional): per-workgroup per-channel sum / sum of squares of y. */

@@ -43,11 +43,37 @@ struct GemmTN {
     int ldo;              // output row stride in elements
     int split;            // E_F32_SPLIT: columns per half
     int Co;               // E_CONVT: channels per tap
+    int wshift, hshift;   // log2(W), log2(H) when both are powers of two, else -1
     double flops, bytes;  // algorithmic work of this launch (profiling only)
 };
 
+// GEMM row m -> pixel (img, h, w) of the H x W grid (shifts when the grid is a power of two)
+__device__ __forceinline__ void split_px(const GemmTN& p, int m, int& w, int& h, int& img) {
+    if (p.W <= 0) { w = h = img = 0; return; }
+    if (p.wshift >= 0 && p.hshift >= 0) {
+        w = m & (p.W - 1);
+        h = (m >> p.wshift) & (p.H - 1);
+        img = m >> (p.wshift + p.hshift);
+    } else {
+        w = m % p.W;
+        const int t = m / p.W;
+        h = t % p.H;
+        img = t / p.H;
+    }
+}
+
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+
+// sum over the 16 lanes of a DPP row (lanes sharing lane >> 4): four v_add_f32 with DPP operand
+// swizzles (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror), no LDS traffic.
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+    return v;
+}
 
 template <int BM, int BN, int BK, int WAVES_M, int AMODE, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
@@ -83,19 +109,18 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
         a_ok[i] = m < p.M;
         a_hw[i] = 0;
         a_chunk[i] = chunk;
+        int w, h, img;
+        split_px(p, m, w, h, img);
         if (AMODE == A_CONV3_C8) {
-            const int w = m % p.W, t = m / p.W, h = t % p.H, img = t / p.H;
-            a_off[i] = (((long)img * p.H + h) * p.W + w) * 8;
+            a_off[i] = (long)m * 8;
             a_hw[i] = (h << 16) | w;
         } else if (AMODE == A_PLAIN) {
             a_off[i] = (long)m * p.lda + chunk * 8;
         } else if (AMODE == A_CONV3) {
-            const int w = m % p.W, t = m / p.W, h = t % p.H, img = t / p.H;
-            a_off[i] = (((long)img * p.H + h) * p.W + w) * p.C + chunk * 8;
+            a_off[i] = (long)m * p.C + chunk * 8;
             a_hw[i] = (h << 16) | w;
         } else {
-            const int j = m % p.W, t = m / p.W, ii = t % p.H, img = t / p.H;
-            a_off[i] = (((long)img * 2 * p.H + 2 * ii) * (2 * p.W) + 2 * j) * p.C + chunk * 8;
+            a_off[i] = (((long)img * 2 * p.H + 2 * h) * (2 * p.W) + 2 * w) * p.C + chunk * 8;
         }
     }
     long b_off[B_INSTR];
@@ -213,7 +238,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
         const bool mok = m < p.M;
         long orow = 0;
         if (EPI == E_CONVT) {
-            const int jj = m % p.W, t = m / p.W, ii = t % p.H, img = t / p.H;
+            int jj, ii, img;
+            split_px(p, m, jj, ii, img);
             orow = ((long)img * 2 * p.H + 2 * ii) * (2 * p.W) + 2 * jj;
         }
 #pragma unroll
@@ -254,12 +280,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
         for (int j = 0; j < FN; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float s = ssum[j][r], q = ssq[j][r];
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    s += __shfl_xor(s, o, 64);
-                    q += __shfl_xor(q, o, 64);
-                }
+                const float s = row16_sum(ssum[j][r]), q = row16_sum(ssq[j][r]);
                 if ((lane & 15) == 0) {
                     const int c = wn * TN + j * 16 + (lane >> 4) * 4 + r;
                     red[wm * BN + c] = s;
@@ -288,9 +309,30 @@ static int launch_one(const GemmTN& p, hipStream_t s) {
     return 0;
 }
 
+static int ilog2_exact(int v) {
+    if (v <= 0 || (v & (v - 1))) return -1;
+    int s = 0;
+    while ((1 << s) < v) ++s;
+    return s;
+}
+
+// rows of the M dimension per workgroup: 128, or 64 when 128-row tiles would leave CUs idle
+static int pick_bm(long M, int N) {
+    const long bn = N <= 64 ? 64 : 128;
+    const long blocks = ((M + 127) / 128) * ((N + bn - 1) / bn);
+    return blocks < 256 ? 64 : 128;
+}
+
 template <int AMODE, int EPI>
-static int launch_bk64(const GemmTN& p, hipStream_t s) {
-    if (p.N <= 64) return launch_one<128, 64, 64, 4, AMODE, EPI>(p, s);
+static int launch_bk64(GemmTN p, hipStream_t s) {
+    p.wshift = ilog2_exact(p.W);
+    p.hshift = ilog2_exact(p.H);
+    const bool small = pick_bm(p.M, p.N) == 64;
+    if (p.N <= 64) {
+        if (small) return launch_one<64, 64, 64, 2, AMODE, EPI>(p, s);
+        return launch_one<128, 64, 64, 4, AMODE, EPI>(p, s);
+    }
+    if (small) return launch_one<64, 128, 64, 2, AMODE, EPI>(p, s);
     return launch_one<128, 128, 64, 2, AMODE, EPI>(p, s);
 }
 
@@ -309,7 +351,12 @@ static int check_common(const GemmTN& p, int bk, const char* who) {
 
 using namespace vae;
 
-extern "C" int vae_gemm_rows_per_block(void) { return 128; }
+extern "C" int vae_gemm_rows_per_block(void) { return 64; }   // the smallest tile: an upper bound on partial rows
+
+extern "C" int vae_gemm_stat_rows(long M, int N) {
+    const int bm = pick_bm(M, N);
+    return (int)((M + bm - 1) / bm);
+}
 
 extern "C" int vae_conv3x3_gemm(const void* x, const void* w_packed, const float* bias, void* y,
                                 float* stat_sum, float* stat_sq, int n_img, int H, int W, int Cin,
