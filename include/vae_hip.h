@@ -130,6 +130,14 @@ int vae_wgrad_ksplit(int M, int N, int taps, long Ktot);
  * (ignored for PLAIN). */
 int vae_wgrad_gemm(const void* P, const void* Q, float* slab, int M, int N, long Ktot, int ldp,
                    int ldq, int mode, int H, int W, int nsplit, void* stream);
+/* Conv2d 3x3 weight gradient with all nine taps per workgroup (one staged input patch serves
+ * the nine shifts).  Same slab layout as VAE_WGRAD_CONV3: [split][Cout][9][Cin].  Covers
+ * power-of-two images with 4 <= W <= 64 and channel counts that are multiples of 64
+ * (vae_conv3_wgrad_patch_ok); other shapes go through vae_wgrad_gemm. */
+int vae_conv3_wgrad_patch_ok(int H, int W, int Cin, int Cout);
+int vae_conv3_wgrad_patch_ksplit(int n_img, int H, int W, int Cin, int Cout);
+int vae_conv3_wgrad_patch(const void* dy, const void* x, float* slab, int n_img, int H, int W,
+                          int Cin, int Cout, int nsplit, void* stream);
 /* out[e] (+)= sum_s slab[s*slab_stride + base + i0*s0+i1*s1+i2*s2+i3*s3] where e is the row-major
  * index over dims4 = (D0,D1,D2,D3): folds the K splits and converts the kernels' packed
  * layout to the parameter's own layout (e.g. Conv2d [Cout][Cin][3][3]). */

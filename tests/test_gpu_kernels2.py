@@ -109,6 +109,36 @@ def test_conv3x3_wgrad(L, n, H, W, Ci, Co):
     assert rel_l2(dw.cpu(), 2 * w.grad) <= 1e-4
 
 
+@pytest.mark.parametrize("n,H,W,Ci,Co,ns", [
+    (5, 4, 4, 256, 64, 0), (3, 4, 4, 64, 64, 1), (3, 8, 8, 128, 64, 0), (2, 16, 16, 64, 128, 2), (2, 32, 32, 64, 64, 0),
+    (1, 64, 64, 64, 64, 7), (9, 2, 4, 64, 64, 0), (1, 16, 8, 64, 64, 0), (64, 8, 8, 128, 256, 0)])
+def test_conv3x3_wgrad_patch(L, n, H, W, Ci, Co, ns):
+    """nine-taps-per-workgroup kernel == autograd's Conv2d weight gradient (images smaller than, equal to and
+    larger than a 64-pixel K tile, ragged last tile, forced and suggested K splits)"""
+    assert L.call("vae_conv3_wgrad_patch_ok", H, W, Ci, Co) == 1
+    g = torch.Generator().manual_seed(n + H + Ci)
+    x = bf(torch.randn(n, Ci, H, W, generator=g))
+    dy = bf(torch.randn(n, Co, H, W, generator=g))
+    w = torch.zeros(Co, Ci, 3, 3, requires_grad=True)
+    F.conv2d(x, w, None, padding=1).backward(dy)
+    xd, dyd = nhwc(x), nhwc(dy)
+    s = ns or L.call("vae_conv3_wgrad_patch_ksplit", n, H, W, Ci, Co)
+    assert 1 <= s <= (n * H * W + 63) // 64
+    slab = torch.full((s, Co, 9, Ci), float("nan"), device=DEV)
+    L.call("vae_conv3_wgrad_patch", L.ptr(dyd), L.ptr(xd), L.ptr(slab), n, H, W, Ci, Co, s, L.current_stream())
+    dw = slab.sum(0).permute(0, 2, 1).reshape(Co, Ci, 3, 3)
+    assert rel_l2(dw.cpu(), w.grad) <= 1e-4
+
+
+def test_conv3x3_wgrad_patch_rejects(L):
+    assert L.call("vae_conv3_wgrad_patch_ok", 6, 6, 64, 64) == 0
+    assert L.call("vae_conv3_wgrad_patch_ok", 8, 8, 32, 64) == 0
+    assert L.call("vae_conv3_wgrad_patch_ok", 128, 128, 64, 64) == 0
+    t = torch.zeros(64, device=DEV)
+    with pytest.raises(RuntimeError, match="not covered"):
+        L.call("vae_conv3_wgrad_patch", L.ptr(t), L.ptr(t), L.ptr(t), 1, 6, 6, 64, 64, 1, L.current_stream())
+
+
 @pytest.mark.parametrize("n,H,W,Ci,Co", [(2, 4, 4, 256, 128), (3, 8, 8, 128, 64), (2, 16, 16, 64, 64), (1, 3, 5, 64, 64)])
 def test_convt_wgrad(L, n, H, W, Ci, Co):
     g = torch.Generator().manual_seed(n + H + Ci)

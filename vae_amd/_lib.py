@@ -39,6 +39,9 @@ SIGNATURES = {
     "vae_conv3x3_c8_gemm": (None, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "vae_wgrad_ksplit": (c_int, [c_int, c_int, c_int, c_long]),
     "vae_wgrad_gemm": (None, [P, P, P, c_int, c_int, c_long, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "vae_conv3_wgrad_patch_ok": (c_int, [c_int, c_int, c_int, c_int]),
+    "vae_conv3_wgrad_patch_ksplit": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "vae_conv3_wgrad_patch": (None, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "vae_reduce_slabs": (None, [P, c_int, c_long, P, P, P, c_long, c_int, P]),
     "vae_pack_bf16": (None, [P, P, P, P, c_long, P]),
     "vae_bn_finalize": (None, [P, P, c_int, c_int, c_int, c_double, P, P, P, P, c_float, c_float, c_int,

@@ -1,0 +1,236 @@
+// 3x3 conv weight gradient, all nine taps per workgroup ("patch" form of the NT GEMM):
+//
+//   dW[co][tap][ci] = sum_pix dY[pix][co] * X[pix + tap][ci]
+//
+// A workgroup owns a 64(co) x 64(ci) block of the weight tensor for ALL 9 taps and walks a range of
+// 64-pixel K tiles.  Per K tile it stages the dY rows once (8 KB) and the input PATCH once: the
+// tile's pixels plus a one-pixel halo, zero where the halo leaves the image (<= 25 KB), instead of
+// nine shifted copies of the tile -- 5.6x fewer bytes through L2/LDS per FLOP than one tap per
+// workgroup, and dY is read once instead of nine times.  The nine taps are then nine row-shifted
+// transposing reads (ds_read_b64_tr_b16) of the same patch.  Each wave owns 16 input channels x all 64 output
+// channels x 9 taps (36 MFMA tiles, 144 VGPRs), so the dY fragments are read once per 9 taps.  K is split over gridDim.z into slabs [split][co][tap][ci] exactly like the
+// one-tap kernel, so the same reducer folds them.
+//
+// Geometry: a K tile is 64 consecutive pixels = G groups of R image rows (R*W*G = 64); with
+// H*W >= 64 that is one group of 64/W rows of one image, for smaller images 64/(H*W) whole images.
+// Patch row of pixel (g, r, x), r in [-1, R], x in [-1, W]:  (g*(R+2) + r+1)*(W+2) + x+1.
+#include "common.h"
+#include "prof.h"
+#include "../../include/vae_hip.h"
+
+namespace vae {
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+typedef __attribute__((address_space(3))) short4v* l4ptr_t;
+
+struct PatchP {
+    const bf16_t* P;   // dY [Ktot][Co]
+    const bf16_t* Q;   // X  [Ktot][Ci]
+    float* slab;
+    int Co, Ci, Ktot;
+    int H, W, wshift;
+    int R, G, rwshift;     // rows per group, groups per tile, log2(R*W)
+    int PR;                // patch rows
+    int ktiles, kps;       // K tiles in total / per split
+    long slab_stride;
+};
+
+constexpr int PATCH_ROWS_MAX = 200;                   // >= 3*(64+2) = 198, multiple of 8
+constexpr int PATCH_INSTR_PER_WAVE = (PATCH_ROWS_MAX / 8 + 3) / 4;   // 7
+constexpr int ROWB = 128;                             // 64 channels of bf16
+
+__device__ __forceinline__ int swz128(int row) { return (((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1; }
+
+// transposing fragment: lanes 16g..16g+15 take rows row_lo + (t>>2) and row_hi + (t>>2) (4 each) of
+// columns col0..col0+15; lane (l & 15) ends up with 8 consecutive k of column col0 + (l & 15)
+__device__ __forceinline__ bf16x8 tr_frag2(const unsigned char* base, int row_lo, int row_hi, int col0, int lane) {
+    const int t = lane & 15;
+    const int off = (col0 + 4 * (t & 3)) * 2;
+    const int chunk = off >> 4, within = off & 15;
+    const int ra = row_lo + (t >> 2), rb = row_hi + (t >> 2);
+    const unsigned char* a = base + ra * ROWB + (((chunk ^ swz128(ra)) << 4) | within);
+    const unsigned char* b = base + rb * ROWB + (((chunk ^ swz128(rb)) << 4) | within);
+    const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((l4ptr_t)(a));
+    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((l4ptr_t)(b));
+    typedef __attribute__((ext_vector_type(8))) short short8v;
+    const short8v v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(256, 2) void conv3_wgrad_patch_kernel(const PatchP p) {
+    constexpr int P_BYTES = 64 * ROWB, Q_BYTES = PATCH_ROWS_MAX * ROWB, STAGE = P_BYTES + Q_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * 64, m0 = blockIdx.y * 64, split = blockIdx.z;
+    const int kt_beg = split * p.kps, kt_end = min(kt_beg + p.kps, p.ktiles);
+    const bf16_t* zero = (const bf16_t*)g_zero_page;
+    const int W2 = p.W + 2;
+
+    // ---- per-lane patch staging state (the lane's patch rows never change) -------------
+    // packed: bits 0-7 pixel offset inside the tile + 128, 8-15 image-row offset r + 1, 16-18 source chunk,
+    // bit 24 "row holds a pixel" (else padding: left/right halo or past the patch)
+    int q_st[PATCH_INSTR_PER_WAVE];
+    const int ninstr = (p.PR + 7) >> 3;
+#pragma unroll
+    for (int i = 0; i < PATCH_INSTR_PER_WAVE; ++i) {
+        const int prow = (wave + 4 * i) * 8 + (lane >> 3);
+        int st = ((lane & 7) ^ swz128(prow)) << 16;
+        if (prow < p.PR) {
+            const int per = (p.R + 2) * W2;
+            const int g = prow / per, rem = prow - g * per;
+            const int rr = rem / W2, xx = rem - rr * W2;
+            if (xx >= 1 && xx <= p.W) st |= ((g * p.R + (rr - 1)) * p.W + (xx - 1) + 128) | (rr << 8) | (1 << 24);
+        }
+        q_st[i] = st;
+    }
+    const int p_row0 = wave * 8 + (lane >> 3);
+    const int p_ch0 = (lane & 7) ^ swz128(p_row0);
+
+    auto stage = [&](int buf, int kt) {
+        unsigned char* pbase = smem + buf * STAGE;
+        unsigned char* qbase = pbase + P_BYTES;
+        const int k0 = kt * 64;
+        {
+            int ra = p_row0, ca = p_ch0;
+            asm volatile("" : "+v"(ra), "+v"(ca));
+            const int ka = k0 + ra, kb = ka + 32;
+            const int cb = ca;                // rows 32 apart agree in both swizzle bits
+            const unsigned char* pcol = (const unsigned char*)(p.P + m0);
+            const unsigned prow = (unsigned)p.Co * 2;
+            const unsigned char* sa = ka < p.Ktot ? pcol + ((unsigned)ka * prow + ca * 16) : (const unsigned char*)zero;
+            const unsigned char* sb = kb < p.Ktot ? pcol + ((unsigned)kb * prow + cb * 16) : (const unsigned char*)zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)sa, (lptr_t)(pbase + wave * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)sb, (lptr_t)(pbase + (wave + 4) * 1024), 16, 0, 0);
+        }
+        const unsigned char* qcol = (const unsigned char*)(p.Q + n0);
+        const unsigned rowb = (unsigned)p.Ci * 2;
+        const int h0 = p.G == 1 ? ((k0 >> p.wshift) & (p.H - 1)) : 0;
+#pragma unroll
+        for (int i = 0; i < PATCH_INSTR_PER_WAVE; ++i) {
+            if (wave + 4 * i < ninstr) {     // wave-uniform
+                const unsigned char* src = (const unsigned char*)zero;
+                int st = q_st[i];
+                asm volatile("" : "+v"(st));      // keep the unpacking inside the loop (registers are scarce here)
+                const int k = k0 + (st & 255) - 128, r = ((st >> 8) & 255) - 1;
+                if ((st >> 24) && (unsigned)(h0 + r) < (unsigned)p.H && (unsigned)k < (unsigned)p.Ktot)
+                    src = qcol + ((unsigned)k * rowb + ((st >> 12) & 0x70));
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(qbase + (wave + 4 * i) * 1024), 16, 0, 0);
+            }
+        }
+    };
+
+    f32x4 acc[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // patch row of tile pixel k (k % 4 == 0)
+    auto prow_of = [&](int k) {
+        const int g = k >> p.rwshift, kr = k & ((1 << p.rwshift) - 1);
+        const int r = kr >> p.wshift, x = kr & (p.W - 1);
+        return (g * (p.R + 2) + r + 1) * W2 + x + 1;
+    };
+
+    if (kt_beg < kt_end) stage(0, kt_beg);
+    for (int kt = kt_beg; kt < kt_end; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < kt_end) stage((kt + 1 - kt_beg) & 1, kt + 1);
+        const unsigned char* pbase = smem + ((kt - kt_beg) & 1) * STAGE;
+        const unsigned char* qbase = pbase + P_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int kq = kk * 32 + 8 * (lane >> 4);          // this lane group's 8 pixels
+            bf16x8 pb[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pb[j] = tr_frag2(pbase, kq, kq + 4, j * 16, lane);
+            const int r_lo = prow_of(kq), r_hi = prow_of(kq + 4);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int sh = (t / 3 - 1) * W2 + (t % 3 - 1);
+                const bf16x8 qa = tr_frag2(qbase, r_lo + sh, r_hi + sh, wave * 16, lane);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, pb[j], acc[t][j], 0, 0, 0);
+            }
+        }
+    }
+
+    // acc[t][j][r]: ci = n0 + wave*16 + (lane>>4)*4 + r ; co = m0 + j*16 + (lane&15)
+    float* out = p.slab + (long)split * p.slab_stride;
+    const int ci = n0 + wave * 16 + (lane >> 4) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int co = m0 + j * 16 + (lane & 15);
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+            *(float4*)(out + ((long)co * 9 + t) * p.Ci + ci) = make_float4(acc[t][j][0], acc[t][j][1], acc[t][j][2], acc[t][j][3]);
+    }
+}
+
+static int ilog2x(int v) {
+    if (v <= 0 || (v & (v - 1))) return -1;
+    int s = 0;
+    while ((1 << s) < v) ++s;
+    return s;
+}
+
+}  // namespace vae
+
+using namespace vae;
+
+// 1 when the patch kernel covers this geometry (power-of-two image with 4 <= W <= 64, whole K tiles
+// inside images or whole images inside K tiles, channel counts multiples of 64)
+extern "C" int vae_conv3_wgrad_patch_ok(int H, int W, int Cin, int Cout) {
+    if (ilog2x(H) < 0 || ilog2x(W) < 0 || W < 4 || W > 64) return 0;
+    if (Cin % 64 || Cout % 64) return 0;
+    const long hw = (long)H * W;
+    if (hw >= 64) return 64 % W == 0 ? 1 : 0;
+    return 64 % hw == 0 ? 1 : 0;
+}
+
+extern "C" int vae_conv3_wgrad_patch_ksplit(int n_img, int H, int W, int Cin, int Cout) {
+    const long ktiles = ((long)n_img * H * W + 63) / 64;
+    const long tiles = (long)(Cin / 64) * (Cout / 64);
+    long s = (256 + tiles - 1) / tiles;
+    const long maxs = ktiles / 4 > 0 ? ktiles / 4 : 1;
+    if (s > maxs) s = maxs;
+    if (s > 256) s = 256;
+    if (s < 1) s = 1;
+    const long kps = (ktiles + s - 1) / s;
+    return (int)((ktiles + kps - 1) / kps);
+}
+
+extern "C" int vae_conv3_wgrad_patch(const void* dy, const void* x, float* slab, int n_img, int H, int W, int Cin,
+                                     int Cout, int nsplit, void* stream) {
+    VAE_CHECK(dy && x && slab, "vae_conv3_wgrad_patch: null pointer");
+    VAE_CHECK(n_img > 0 && vae_conv3_wgrad_patch_ok(H, W, Cin, Cout),
+              "vae_conv3_wgrad_patch: geometry n=%d %dx%d Cin=%d Cout=%d not covered (use vae_wgrad_gemm)", n_img, H, W, Cin, Cout);
+    VAE_CHECK((long)n_img * H * W * (Cin > Cout ? Cin : Cout) * 2 < (1L << 32), "vae_conv3_wgrad_patch: operand larger than 4 GiB");
+    VAE_CHECK((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)slab) & 15) == 0, "vae_conv3_wgrad_patch: operands must be 16-byte aligned");
+    PatchP p = {};
+    p.P = (const bf16_t*)dy; p.Q = (const bf16_t*)x; p.slab = slab;
+    p.Co = Cout; p.Ci = Cin; p.Ktot = n_img * H * W;
+    p.H = H; p.W = W; p.wshift = ilog2x(W);
+    const long hw = (long)H * W;
+    if (hw >= 64) { p.G = 1; p.R = 64 / W; } else { p.G = (int)(64 / hw); p.R = H; }
+    p.rwshift = ilog2x(p.R * W);
+    p.PR = p.G * (p.R + 2) * (W + 2);
+    VAE_CHECK(p.PR <= PATCH_ROWS_MAX && p.rwshift >= 0, "vae_conv3_wgrad_patch: internal geometry error");
+    p.ktiles = (p.Ktot + 63) / 64;
+    VAE_CHECK(nsplit >= 1 && nsplit <= p.ktiles, "vae_conv3_wgrad_patch: nsplit=%d out of range (1..%d)", nsplit, p.ktiles);
+    p.kps = (p.ktiles + nsplit - 1) / nsplit;
+    VAE_CHECK((long)(nsplit - 1) * p.kps < p.ktiles, "vae_conv3_wgrad_patch: nsplit=%d leaves empty splits", nsplit);
+    p.slab_stride = 9L * Cout * Cin;
+    dim3 grid(Cin / 64, Cout / 64, nsplit);
+    hipStream_t s = (hipStream_t)stream;
+    const double flops = 2.0 * Cout * Cin * 9.0 * p.Ktot;
+    const double bytes = 2.0 * p.Ktot * ((double)Cout + Cin) + 4.0 * nsplit * 9.0 * Cout * Cin;
+    ProfScope prof("conv3_wgrad_patch_kernel", flops, bytes, s);
+    hipLaunchKernelGGL(conv3_wgrad_patch_kernel, grid, dim3(256), 0, s, p);
+    VAE_LAUNCH_CHECK("conv3_wgrad_patch_kernel");
+    return 0;
+}

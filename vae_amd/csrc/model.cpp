@@ -184,7 +184,11 @@ void make_ws_layout(const Dims& d, WsLayout* w) {
     for (int i = 0; i < 7; ++i) {
         const int b = (i + 1) / 2;     // encoder block of conv i (c1b -> 0, c2a,c2b -> 1, ...)
         const long h = d.S >> b;
-        const long v = slab_need(CONV_CO[i], CONV_CI[i], 9, (long)d.N * h * h);
+        long v = slab_need(CONV_CO[i], CONV_CI[i], 9, (long)d.N * h * h);
+        if (vae_conv3_wgrad_patch_ok((int)h, (int)h, CONV_CI[i], CONV_CO[i])) {
+            const long vp = (long)vae_conv3_wgrad_patch_ksplit(d.N, (int)h, (int)h, CONV_CI[i], CONV_CO[i]) * 9 * CONV_CO[i] * CONV_CI[i];
+            if (vp > v) v = vp;
+        }
         if (v > s) s = v;
     }
     for (int u = 0; u < 3; ++u) {
@@ -435,9 +439,14 @@ static int wgrad_to(const Ctx& c, const void* P, const void* Q, int M, int N, lo
     return vae_wgrad_gemm(P, Q, (float*)c.at(c.ws.slab), M, N, K, ldp, ldq, mode, H, W, ns, c.stream);
 }
 
-static int zero_grad(const Ctx& c, int idx) {
-    CHECK(hipMemsetAsync(c.G(idx), 0, c.pl.numel[idx] * 4, (hipStream_t)c.stream) == hipSuccess, "memset failed");
-    return 0;
+// 3x3 conv weight gradient into the slab: nine-taps-per-workgroup kernel where it applies
+static int conv3_wgrad_to(const Ctx& c, const void* dy, const void* x, int Co, int Ci, int H, int* nsplit_out) {
+    if (vae_conv3_wgrad_patch_ok(H, H, Ci, Co)) {
+        const int ns = vae_conv3_wgrad_patch_ksplit(c.d.N, H, H, Ci, Co);
+        *nsplit_out = ns;
+        return vae_conv3_wgrad_patch(dy, x, (float*)c.at(c.ws.slab), c.d.N, H, H, Ci, Co, ns, c.stream);
+    }
+    return wgrad_to(c, dy, x, Co, Ci, (long)c.d.N * H * H, Co, Ci, VAE_WGRAD_CONV3, H, H, 9, nsplit_out);
 }
 
 // stage 0: head .. fc heads (everything after the encoder); leaves d(encoder output) in g-buffer `cur`
@@ -509,7 +518,7 @@ static int backward_block(const Ctx& c, int b, const void* const* masks) {
     TRY(vae_bn_act_bwd(c.at(w.g0), c.at(w.yb[b]), c.coef(2 * b + 1, 0), c.coef(2 * b + 1, 1), c.coef(2 * b + 1, 2),
                        c.coef(2 * b + 1, 3), (float*)c.at(w.bnpart), c.G(8 * b + 6), c.at(w.g1), d.N, H, H, C, b < 3, p,
                        masks ? masks[b] : nullptr, c.cfg->seed, c.cfg->step, VAE_STREAM_DROPOUT0 + b, c.cfg->rank, c.stream));
-    TRY(wgrad_to(c, c.at(w.g1), c.at(w.aa[b]), C, C, M, C, C, VAE_WGRAD_CONV3, H, H, 9, &ns));
+    TRY(conv3_wgrad_to(c, c.at(w.g1), c.at(w.aa[b]), C, C, H, &ns));
     // slab [co][tap][ci] -> Conv2d weight [co][ci][tap]
     TRY(reduce4((float*)c.at(w.slab), ns, 9L * C * C, 0, c.G(8 * b + 4), C, 9, C, 1, 9L * C, 1, 9, 0, c.stream));
     TRY(vae_conv3x3_gemm(c.at(w.g1), c.pk_at(c.pk.conv_d[2 * b]), nullptr, c.at(w.g0), nullptr, nullptr, d.N, H, H, C, C,
@@ -523,7 +532,7 @@ static int backward_block(const Ctx& c, int b, const void* const* masks) {
         return reduce4((float*)c.at(w.slab), ns, 64L * 128, 0, c.G(0), 64, 16, 8, 1, 9L * d.Cin, 1, 9, 0, c.stream, 9, d.Cin);
     }
     const int Ci = ENC_C[b - 1];
-    TRY(wgrad_to(c, c.at(w.g1), c.at(w.ob[b - 1]), C, Ci, M, C, Ci, VAE_WGRAD_CONV3, H, H, 9, &ns));
+    TRY(conv3_wgrad_to(c, c.at(w.g1), c.at(w.ob[b - 1]), C, Ci, H, &ns));
     TRY(reduce4((float*)c.at(w.slab), ns, 9L * C * Ci, 0, c.G(8 * b), C, 9, Ci, 1, 9L * Ci, 1, 9, 0, c.stream));
     return vae_conv3x3_gemm(c.at(w.g1), c.pk_at(c.pk.conv_d[2 * b - 1]), nullptr, c.at(w.g0), nullptr, nullptr, d.N, H, H, C,
                             Ci, c.stream);
