@@ -1,0 +1,131 @@
+"""CPU checks of the C-ABI boundary: the shared library loads without a GPU, exports every
+function include/vae_hip.h declares, the ctypes table binds exactly that set, and the
+host-only entry points (sizes, layouts, thresholds, geometry predicates) answer correctly.
+No kernel is launched here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import vae_amd._lib as L
+from oracle import vae_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "vae_hip.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", "", src)
+    src = re.sub(r"^\s*#.*$", "", src, flags=re.M)
+    names = re.findall(r"\b(vae_[a-z0-9_]+)\s*\(", src)
+    return sorted(set(names))
+
+
+def test_header_declares_functions():
+    names = declared_functions()
+    assert len(names) >= 50
+    for must in ("vae_model_forward", "vae_model_backward", "vae_conv3x3_gemm", "vae_reparam_kl_fwd",
+                 "vae_recon_loss_fwd_bwd", "vae_adamw_clip_step", "vae_last_error", "vae_version"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    assert os.path.exists(L.LIB_PATH), "build the library first: make -C vae_amd/csrc"
+    lib = ctypes.CDLL(L.LIB_PATH)
+    missing = [n for n in declared_functions() if not hasattr(lib, n)]
+    assert not missing, f"declared in include/vae_hip.h but not exported: {missing}"
+
+
+def test_ctypes_table_matches_header():
+    declared = set(declared_functions())
+    bound = set(L.SIGNATURES)
+    assert bound <= declared, f"bound but not declared: {sorted(bound - declared)}"
+    assert declared <= bound, f"declared but not bound: {sorted(declared - bound)}"
+
+
+def test_no_torch_types_in_header():
+    src = open(HEADER).read()
+    assert 'extern "C"' in src
+    for bad in ("at::", "torch::", "c10::", "std::"):
+        assert bad not in src
+
+
+def test_version_and_error_string():
+    lib = L.load()
+    assert lib.vae_version() >= 1
+    assert isinstance(lib.vae_last_error(), bytes)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "LIB_PATH", os.path.join(ROOT, "does_not_exist.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        L.load()
+
+
+def _cfg(batch, latent, size, cin=3, cout=3):
+    return L.ModelCfg(batch=batch, in_channels=cin, out_channels=cout, latent=latent, image_size=size, train=1,
+                      p_dropout=0.1, seed=1337, step=0, rank=0)
+
+
+@pytest.mark.parametrize("latent,size,total", [(128, 32, 4086787), (256, 64, 15109379), (512, 32, 8806147)])
+def test_flat_parameter_layout_matches_state_dict_order(latent, size, total):
+    """the flat fp32 buffer holds the 52 parameters back to back in the reference's state_dict order with the
+    reference's shapes (vae/models/vae.py:34-74); totals are the parameter counts of the three benchmark models"""
+    cfg = _cfg(8, latent, size)
+    shapes = O.state_shapes(3, 3, latent, size)
+    params = [(k, s) for k, s in shapes.items()
+              if not k.endswith(("running_mean", "running_var", "num_batches_tracked"))]
+    assert len(params) == 52
+    off = 0
+    for i, (name, shape) in enumerate(params):
+        assert L.call("vae_model_param_offset", ctypes.byref(cfg), i) == off, name
+        n = 1
+        for d in shape:
+            n *= d
+        off += n
+    assert off == total
+    # the buffer length is the parameter count rounded up to whole float4s (the optimizer streams float4)
+    assert L.call("vae_model_param_count", ctypes.byref(cfg)) == (total + 3) // 4 * 4
+    # running_mean and running_var of the 11 BatchNorm layers
+    assert L.call("vae_model_bn_count", ctypes.byref(cfg)) == sum(
+        s[0] for k, s in shapes.items() if k.endswith(("running_mean", "running_var")))
+
+
+def test_workspace_is_deterministic_and_grows_with_batch():
+    a = L.call("vae_model_workspace_bytes", ctypes.byref(_cfg(64, 128, 32)))
+    b = L.call("vae_model_workspace_bytes", ctypes.byref(_cfg(512, 128, 32)))
+    assert a == L.call("vae_model_workspace_bytes", ctypes.byref(_cfg(64, 128, 32)))
+    assert 0 < a < b < (8 << 30)
+    assert L.call("vae_model_wpack_bytes", ctypes.byref(_cfg(64, 128, 32))) > 2 * 4086787 * 0.9
+
+
+def test_bad_model_config_is_an_error_not_a_crash():
+    lib = L.load()
+    bad = _cfg(8, 128, 20)          # three 2x2 pools need a multiple of 8
+    assert lib.vae_model_workspace_bytes(ctypes.byref(bad)) < 0
+    assert b"image_size" in lib.vae_last_error()
+
+
+@pytest.mark.parametrize("p", [0.0, 0.1, 0.25, 0.5, 0.9])
+def test_dropout_threshold_matches_oracle(p):
+    assert L.call("vae_dropout_threshold", p) == O.dropout_threshold(p)
+
+
+def test_geometry_helpers():
+    assert L.call("vae_gemm_rows_per_block") in (64, 128)
+    for M, N, taps, K in [(64, 64, 9, 524288), (256, 256, 9, 8192), (4096, 128, 1, 512), (128, 64, 4, 131072)]:
+        s = L.call("vae_wgrad_ksplit", M, N, taps, K)
+        chunk = -(-K // s)
+        assert s >= 1 and (s - 1) * chunk < K
+    assert L.call("vae_conv3_wgrad_patch_ok", 32, 32, 64, 64) == 1
+    assert L.call("vae_conv3_wgrad_patch_ok", 4, 4, 256, 256) == 1
+    assert L.call("vae_conv3_wgrad_patch_ok", 6, 6, 64, 64) == 0
+    assert L.call("vae_conv3_wgrad_patch_ok", 32, 32, 3, 64) == 0
+    for n, H, Ci, Co in [(512, 32, 64, 64), (512, 4, 256, 256), (1, 8, 64, 64)]:
+        s = L.call("vae_conv3_wgrad_patch_ksplit", n, H, H, Ci, Co)
+        assert 1 <= s <= (n * H * H + 63) // 64
+    assert L.call("vae_recon_loss_grid", 1) >= 1 and L.call("vae_reparam_grid", 1) >= 1 and L.call("vae_adamw_grid", 1) >= 1

@@ -1,0 +1,112 @@
+"""world_size-2 CPU (gloo) tests of the data-parallel exchange: per-stage bucketed all-reduce
+of the flat gradient buffer gives every rank the mean gradient, bucket by bucket, and the
+gradient exchange of a data-parallel step (each rank: loss and grads of its own half batch with
+per-rank BatchNorm statistics, then the mean over ranks in backward-stage order) leaves both
+ranks with the same buffer, equal to the single-process mean of the per-rank gradients.  The
+oracle supplies the per-rank arithmetic so the test needs no GPU."""
+import os
+import socket
+import tempfile
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import vae_oracle as O
+from vae_amd import dp
+
+WORLD = 2
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _flat_layout(shapes):
+    names = [k for k in shapes if not k.endswith(("running_mean", "running_var", "num_batches_tracked"))]
+    offsets, o = [], 0
+    for k in names:
+        n = 1
+        for d in shapes[k]:
+            n *= d
+        offsets.append((o, n))
+        o += n
+    return names, offsets, o
+
+
+def _rank_grads(rank, state, shapes):
+    """loss and grads of this rank's half of a fixed global batch (eval-free, dropout off)."""
+    torch.manual_seed(1234)
+    x = torch.rand(8, 3, 16, 16)
+    eps = torch.randn(8, 8)
+    xs, es = x[rank * 4:(rank + 1) * 4], eps[rank * 4:(rank + 1) * 4]
+    loss, _, _, _, grads, _ = O.loss_and_grads(xs, state, es, kind="l1", kl_weight=1.0, train=True, p_dropout=0.0)
+    return loss, grads
+
+
+def _worker(rank, port, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    try:
+        torch.set_num_threads(2)
+        # ---- 1. plain reducer semantics on a synthetic buffer
+        total = 1000
+        g = torch.arange(total, dtype=torch.float32) * (rank + 1)
+        red = dp.BucketedReducer(g, [(600, 1000), (250, 600), (0, 250)], bucket_bytes=4 * 128)
+        assert [len(b) for b in red.buckets] == [4, 3, 2]
+        for s in range(3):
+            red.stage_done(s)
+        red.wait()
+        expect = torch.arange(total, dtype=torch.float32) * 1.5
+        assert torch.equal(g, expect)
+        assert red.handles == []
+
+        # ---- 2. a data-parallel step with the oracle's arithmetic
+        shapes = O.state_shapes(3, 3, 8, 16)
+        names, offsets, n_total = _flat_layout(shapes)
+        torch.manual_seed(99)
+        state = O.construct_state(3, 3, 8, 0.0, 16)
+        # same start on every rank (what broadcast_state does for the GPU model)
+        for k in sorted(state):
+            dist.broadcast(state[k], 0)
+        loss, grads = _rank_grads(rank, state, shapes)
+        flat = torch.zeros(n_total)
+        for k, (o, n) in zip(names, offsets):
+            flat[o:o + n] = grads[k].reshape(-1)
+        red = dp.BucketedReducer(flat, dp.stage_ranges(offsets, n_total), bucket_bytes=64 << 10)
+        for s in range(3):              # backward order: decoder+heads, conv4+conv3, conv2+conv1
+            red.stage_done(s)
+        red.wait()
+        torch.save({"flat": flat, "loss": loss.detach()}, os.path.join(outdir, f"r{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_bucketed_reducer_two_ranks_gloo():
+    port = _free_port()
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(port, d), nprocs=WORLD, join=True)
+        out = [torch.load(os.path.join(d, f"r{r}.pt"), weights_only=True) for r in range(WORLD)]
+    # every rank holds the same reduced gradient
+    assert torch.equal(out[0]["flat"], out[1]["flat"])
+    # and it is the mean of the per-rank gradients, computed here in one process
+    shapes = O.state_shapes(3, 3, 8, 16)
+    names, offsets, n_total = _flat_layout(shapes)
+    torch.manual_seed(99)
+    state = O.construct_state(3, 3, 8, 0.0, 16)
+    ref = torch.zeros(n_total)
+    losses = []
+    for r in range(WORLD):
+        loss, grads = _rank_grads(r, state, shapes)
+        losses.append(loss.detach())
+        for k, (o, n) in zip(names, offsets):
+            ref[o:o + n] += grads[k].reshape(-1) / WORLD
+    # (fp32 summation order differs with the thread count of the workers, hence a norm-relative bar)
+    assert float((out[0]["flat"] - ref).norm() / ref.norm()) <= 1e-5
+    for r in range(WORLD):
+        assert torch.allclose(out[r]["loss"], losses[r], rtol=1e-5)
+    assert float(ref.abs().sum()) > 0
