@@ -225,7 +225,8 @@ int vae_cast_bf16(const float* src, void* dst_bf16, long n, void* stream);
  * bn_stats       : flat fp32 [running_mean(C) | running_var(C)] for the 11 BatchNorms in module
  *                  order (conv1.net.1, conv1.net.4, ... conv4.net.4, bn3, bn2, bn1).
  * wpack          : bf16 operand copies of the weights, vae_model_wpack_bytes(cfg) bytes, refreshed
- *                  by vae_model_pack_weights after every parameter update.
+ *                  by vae_model_pack_weights after every parameter update.  Zero-fill it once when
+ *                  it is allocated: padding lanes of the first conv's operand are never written.
  * workspace      : vae_model_workspace_bytes(cfg) bytes; holds the activations between forward
  *                  and backward, so one workspace per in-flight batch. */
 typedef struct vae_model_cfg {
@@ -261,7 +262,10 @@ int vae_model_kl_partials(const vae_model_cfg* cfg, void* workspace, const float
  * d_recon (= d loss / d recon), optional external d loss/d mu, d loss/d logvar, and
  * kl_scale * KL (kl_scale = kl_weight / batch when the KL term is not in dmu_ext/dlv_ext).
  * stage -1 = everything; 0 = head..fc_mu/fc_logvar, 1 = conv4+conv3, 2 = conv2+conv1 (in that
- * order) so that gradient all-reduce of finished layers can overlap the rest. */
+ * order) so that gradient all-reduce of finished layers can overlap the rest.
+ * grads must be ZERO when the first stage of a pass starts: the biases in front of a train-mode
+ * BatchNorm (conv*.net.{0,3}.bias, up*.bias) have an identically zero gradient and their slots
+ * are not written.  Every other slot is overwritten, not accumulated into. */
 int vae_model_backward(const vae_model_cfg* cfg, const float* params, const void* wpack, void* workspace,
                        const float* d_recon, const float* recon, const float* mu, const float* logvar,
                        const float* eps_in, const void* const* keep_masks, const float* dmu_ext,

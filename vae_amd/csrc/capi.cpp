@@ -41,11 +41,11 @@ bool prof_enabled() { return g_on; }
 void prof_begin(const char* name, double flops, double bytes, hipStream_t s) {
     if (!g_on || g_rec.size() >= g_cap) return;
     g_rec.push_back({name, flops, bytes});
-    hipEventRecord(g_ev[2 * (g_rec.size() - 1)], s);
+    (void)hipEventRecord(g_ev[2 * (g_rec.size() - 1)], s);   // a failed record only loses this sample
 }
 void prof_end(hipStream_t s) {
     if (!g_on || g_rec.empty() || g_rec.size() > g_cap) return;
-    hipEventRecord(g_ev[2 * (g_rec.size() - 1) + 1], s);
+    (void)hipEventRecord(g_ev[2 * (g_rec.size() - 1) + 1], s);
 }
 }  // namespace vae
 
@@ -79,7 +79,10 @@ extern "C" int vae_prof_stop(char* names, int* launches, double* total_ms, doubl
                              int max_rows) {
     using namespace vae;
     g_on = false;
-    hipDeviceSynchronize();
+    if (hipDeviceSynchronize() != hipSuccess) {
+        set_error("vae_prof_stop: hipDeviceSynchronize failed");
+        return -1;
+    }
     std::map<std::string, int> index;
     std::vector<std::string> order;
     std::vector<int> cnt;
