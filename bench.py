@@ -64,7 +64,7 @@ def profile_pass(step_fn, batches, nsteps=3):
     for k in range(min(n, rows)):
         name = names.raw[64 * k:64 * (k + 1)].split(b"\0")[0].decode()
         t = ms[k] * 1e-3
-        mfma = name.startswith(("gemm_", "conv3_wgrad"))      # the matrix-core kernels; everything else streams HBM
+        mfma = name.startswith(("gemm_", "conv3_"))      # the matrix-core kernels; everything else streams HBM
         rec = {"kernel": name, "launches_per_step": launches[k] / nsteps, "ms_per_step": ms[k] / nsteps,
                "avg_us": 1e3 * ms[k] / max(launches[k], 1), "bound": "mfma" if mfma else "hbm"}
         if mfma:

@@ -162,7 +162,11 @@ def check_bf16(got, ref, what):
 # run the 64-row tiles chosen for small problems
 @pytest.mark.parametrize("n,H,W,Ci,Co", [(2, 4, 4, 64, 64), (3, 8, 8, 64, 128), (2, 16, 16, 128, 128),
                                          (5, 4, 4, 256, 256), (2, 32, 32, 64, 64), (1, 6, 10, 128, 64),
-                                         (128, 16, 16, 128, 128), (64, 32, 32, 64, 64)])
+                                         (128, 16, 16, 128, 128), (64, 32, 32, 64, 64),
+                                         # patch-staged kernel geometries: 8 / 2 / 4 images per tile, a ragged last tile,
+                                         # 64-wide rows, several channel chunks with 256 outputs
+                                         (2048, 4, 4, 64, 128), (513, 8, 8, 128, 64), (1024, 8, 4, 64, 64),
+                                         (8, 64, 64, 64, 64), (40, 32, 32, 128, 256)])
 def test_conv3x3_fwd_dgrad(L, n, H, W, Ci, Co):
     g = torch.Generator().manual_seed(n + H + Ci)
     x = bf(torch.randn(n, Ci, H, W, generator=g))

@@ -1,0 +1,302 @@
+// 3x3 stride-1 pad-1 convolution (forward, and input-gradient with flipped/transposed weights) as a
+// bf16 MFMA implicit GEMM whose activation operand is staged ONCE per 64-channel chunk:
+//
+//   out[pix][n] = bias[n] + sum_{tap, c} X[pix + tap][c] * Wp[n][tap][c]
+//
+// A workgroup owns 128 consecutive NHWC pixels x BN output channels.  For every 64-channel chunk
+// it copies the pixels' PATCH -- the tile plus a one-pixel halo, zeros where the halo leaves the
+// image -- into LDS once, and the nine taps read it at nine row offsets.  The one-tap-per-K-step
+// kernel re-fetches a shifted copy of the tile for every tap (9 x 16 KB per chunk); here the
+// global->LDS traffic per chunk is the patch (<= 37 KB) plus nine weight tiles, which moves the
+// kernel off the L2->LDS fill rate (~70 GB/s per CU) that bounds the one-tap form.
+//
+// Patch geometry: a tile is G groups of R image rows (R*W*G = 128): H*W >= 128 -> one group of 128/W
+// rows of one image, smaller images -> 128/(H*W) whole images.  Patch row of pixel (g, r, x), r in
+// [-1, R], x in [-1, W]:  (g*(R+2) + r+1)*(W+2) + x+1, 128 bytes (64 channels) per row.  The bank
+// swizzle is a function of the patch column only and W is a template parameter, so a vertical tap
+// shift is an immediate offset on the fragment address and a horizontal one selects one of three
+// precomputed addresses.
+//
+// MFMA orientation as in the one-tap kernel: weights are the "A" operand (rows = output channels),
+// pixels the "B" operand (columns), so a lane holds 4 consecutive channels of a pixel per
+// accumulator: 8-byte bf16 NHWC stores, per-channel batch statistics reduce over 16 lanes.
+#include "common.h"
+#include "prof.h"
+#include "../../include/vae_hip.h"
+
+namespace vae {
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+struct PatchTN {
+    const bf16_t* A;      // activations NHWC [M][C]
+    const bf16_t* B;      // packed weights [N][9][C]
+    const float* bias;    // [N] or null
+    bf16_t* out;          // [M][N]
+    float* stat_sum;      // [M/128][N] or null
+    float* stat_sq;
+    int M, N, C;
+    int H, wshift;
+    int R, G, rwshift;    // rows per group, groups per tile, log2(R*W)
+    int PR;               // patch rows
+};
+
+constexpr int PT_BM = 128;
+constexpr int PT_ROWS_MAX = 288;                       // 8 images of 4x4: 8 * 6 * 6
+constexpr int PT_Q_INSTR = PT_ROWS_MAX / 8 / 4;        // global_load_lds instructions per wave: 9
+constexpr int PT_ROWB = 128;
+
+__device__ __forceinline__ float pt_row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+    return v;
+}
+
+template <int W, int BN>
+__global__ __launch_bounds__(256, 2) void conv3_patch_tn_kernel(const PatchTN p) {
+    constexpr int W2 = W + 2;
+    constexpr int WAVES_M = BN == 128 ? 2 : 4, WAVES_N = 4 / WAVES_M;
+    constexpr int TM = PT_BM / WAVES_M, TN = BN / WAVES_N;      // wave tile: TM pixels x TN channels
+    constexpr int FM = TM / 16, FN = TN / 16;
+    constexpr int Q_BYTES = PT_ROWS_MAX * PT_ROWB, B_BYTES = BN * PT_ROWB;
+    constexpr int B_INSTR = BN / 8 / 4;
+    static_assert(TN == 64, "wave tile is 64 channels wide");
+
+    __shared__ __attribute__((aligned(16))) unsigned char smem[Q_BYTES + 2 * B_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int m0 = blockIdx.x * PT_BM, n0 = blockIdx.y * BN;
+    const bf16_t* zero = (const bf16_t*)g_zero_page;
+    const int K = 9 * p.C;
+
+    // ---- patch staging: each lane's patch rows are fixed for the lifetime of the workgroup ----
+    // packed: bits 0-9 pixel offset inside the tile + 256, 10-17 image-row offset r + 1, 18-20 source chunk,
+    // bit 24 "row holds a pixel" (else padding: left/right halo or past the patch)
+    int q_st[PT_Q_INSTR];
+    const int ninstr = (p.PR + 7) >> 3;
+#pragma unroll
+    for (int i = 0; i < PT_Q_INSTR; ++i) {
+        const int prow = (wave + 4 * i) * 8 + (lane >> 3);
+        const int per = (p.R + 2) * W2;
+        const int g = prow / per, rem = prow - g * per;
+        const int rr = rem / W2, xx = rem - rr * W2;
+        int st = ((lane & 7) ^ ((xx >> 1) & 7)) << 18;
+        if (prow < p.PR && xx >= 1 && xx <= W) st |= ((g * p.R + (rr - 1)) * W + (xx - 1) + 256) | (rr << 10) | (1 << 24);
+        q_st[i] = st;
+    }
+    const int h0 = p.G == 1 ? ((m0 >> p.wshift) & (p.H - 1)) : 0;
+    const unsigned rowb = (unsigned)p.C * 2;
+
+    auto stage_patch = [&](int c0) {
+        const unsigned char* acol = (const unsigned char*)(p.A + c0);
+#pragma unroll
+        for (int i = 0; i < PT_Q_INSTR; ++i) {
+            if (wave + 4 * i < ninstr) {     // wave-uniform
+                const unsigned char* src = (const unsigned char*)zero;
+                int st = q_st[i];
+                asm volatile("" : "+v"(st));      // unpack inside the loop: one register per instruction
+                const int m = m0 + (st & 1023) - 256, r = ((st >> 10) & 255) - 1;
+                if ((st >> 24) && (unsigned)(h0 + r) < (unsigned)p.H && (unsigned)m < (unsigned)p.M)
+                    src = acol + ((unsigned)m * rowb + ((st >> 14) & 0x70));
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + (wave + 4 * i) * 1024), 16, 0, 0);
+            }
+        }
+    };
+
+    // ---- weight tile staging -------------------------------------------------------------------
+    int b_off[B_INSTR];     // element offset of this lane's 16-byte chunk for tap 0, channel chunk 0 (-1: row >= N)
+#pragma unroll
+    for (int i = 0; i < B_INSTR; ++i) {
+        const int row = (wave + 4 * i) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        b_off[i] = n0 + row < p.N ? (n0 + row) * K + chunk * 8 : -1;
+    }
+    auto stage_b = [&](int buf, int koff) {      // koff = tap * C + c0
+        unsigned char* bbase = smem + Q_BYTES + buf * B_BYTES;
+#pragma unroll
+        for (int i = 0; i < B_INSTR; ++i) {
+            const bf16_t* src = b_off[i] >= 0 ? p.B + b_off[i] + koff : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(bbase + (wave + 4 * i) * 1024), 16, 0, 0);
+        }
+    };
+
+    // ---- fragment addresses --------------------------------------------------------------------
+    int a_addr[FM][3][2];      // [pixel fragment][dw + 1][kk], tap row dh = -1; (dh + 1) * W2 * 128 is an immediate
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int ml = wm * TM + i * 16 + (lane & 15);
+        const int g = ml >> p.rwshift, kr = ml & ((1 << p.rwshift) - 1);
+        const int r = kr >> p.wshift, x = kr & (W - 1);
+        const int prow = (g * (p.R + 2) + r) * W2 + x + 1;            // the pixel one image row up
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+                a_addr[i][d][kk] = (prow + d - 1) * PT_ROWB + (((kk * 4 + (lane >> 4)) ^ (((x + d) >> 1) & 7)) << 4);
+    }
+    int b_addr[FN][2];
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int row = wn * TN + j * 16 + (lane & 15);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+            b_addr[j][kk] = Q_BYTES + row * PT_ROWB + (((kk * 4 + (lane >> 4)) ^ ((row >> 1) & 7)) << 4);
+    }
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nchunk = p.C / 64;
+    stage_patch(0);
+    stage_b(0, 0);
+    int par = 0;                                   // weight buffer holding the current tap
+    for (int c = 0; c < nchunk; ++c) {
+        const int c0 = c * 64;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tap + 1 < 9) stage_b(par ^ 1, (tap + 1) * p.C + c0);
+            else if (c + 1 < nchunk) stage_b(par ^ 1, c0 + 64);
+            const int dh = tap / 3, dw = tap % 3;
+            const int boff = par * B_BYTES;
+            bf16x8 xa[2][FM], wb[2][FN];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+                    xa[kk][i] = *(const bf16x8*)(smem + a_addr[i][dw][kk] + dh * W2 * PT_ROWB);
+#pragma unroll
+                for (int j = 0; j < FN; ++j) wb[kk][j] = *(const bf16x8*)(smem + b_addr[j][kk] + boff);
+            }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[kk][j], xa[kk][i], acc[i][j], 0, 0, 0);
+            par ^= 1;
+        }
+        if (c + 1 < nchunk) {
+            __syncthreads();            // every wave has read the last tap of this chunk's patch
+            stage_patch(c0 + 64);
+        }
+    }
+
+    // ---- epilogue: bias, bf16 store, per-channel sum / sum of squares of the stored values ----------
+    // acc[i][j][r]: pixel m = m0 + wm*TM + i*16 + (lane&15), channel n = n0 + wn*TN + j*16 + (lane>>4)*4 + r
+    const bool want_stats = p.stat_sum != nullptr;
+    float ssum[FN][4], ssq[FN][4], bv[FN][4];
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int n = n0 + wn * TN + j * 16 + (lane >> 4) * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ssum[j][r] = ssq[j][r] = bv[j][r] = 0.f;
+        if (p.bias && n < p.N) {
+            const float4 b4 = *(const float4*)(p.bias + n);
+            bv[j][0] = b4.x; bv[j][1] = b4.y; bv[j][2] = b4.z; bv[j][3] = b4.w;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int m = m0 + wm * TM + i * 16 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int n = n0 + wn * TN + j * 16 + (lane >> 4) * 4;
+            if (m >= p.M || n >= p.N) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = acc[i][j][r] + bv[j][r];
+                ssum[j][r] += v[r];
+                ssq[j][r] += v[r] * v[r];
+            }
+            *(uint2*)(p.out + (long)m * p.N + n) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+        }
+    }
+    if (want_stats) {
+        __syncthreads();                 // the staging buffers are free
+        float* red = (float*)smem;       // [2][WAVES_M][BN]
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float s = pt_row16_sum(ssum[j][r]), q = pt_row16_sum(ssq[j][r]);
+                if ((lane & 15) == 0) {
+                    const int cc = wn * TN + j * 16 + (lane >> 4) * 4 + r;
+                    red[wm * BN + cc] = s;
+                    red[(WAVES_M + wm) * BN + cc] = q;
+                }
+            }
+        __syncthreads();
+        if (tid < BN && n0 + tid < p.N) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES_M; ++w) { s += red[w * BN + tid]; q += red[(WAVES_M + w) * BN + tid]; }
+            p.stat_sum[(long)blockIdx.x * p.N + n0 + tid] = s;
+            p.stat_sq[(long)blockIdx.x * p.N + n0 + tid] = q;
+        }
+    }
+}
+
+static int pt_ilog2(int v) {
+    if (v <= 0 || (v & (v - 1))) return -1;
+    int s = 0;
+    while ((1 << s) < v) ++s;
+    return s;
+}
+
+template <int W>
+static void pt_launch_w(const PatchTN& p, dim3 grid, int bn, hipStream_t s) {
+    if (bn == 64) hipLaunchKernelGGL((conv3_patch_tn_kernel<W, 64>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((conv3_patch_tn_kernel<W, 128>), grid, dim3(256), 0, s, p);
+}
+
+// 1 when the patch kernel covers the geometry: power-of-two image, 4 <= W <= 64, tiles of 128 pixels that
+// hold whole image rows or whole images, 64-channel chunks, N a multiple of 64
+bool conv3_patch_tn_ok(int n_img, int H, int W, int Cin, int Cout) {
+    if (pt_ilog2(H) < 0 || pt_ilog2(W) < 0 || W < 4 || W > 64) return false;
+    if (Cin % 64 || Cout % 64) return false;
+    const long hw = (long)H * W;
+    if (hw < 128 && (128 % hw || hw < 16)) return false;
+    if ((long)n_img * hw * (Cin > Cout ? Cin : Cout) * 2 >= (1L << 32)) return false;
+    if ((long)Cout * 9 * Cin >= (1L << 30)) return false;
+    return true;
+}
+
+// stat rows written: ceil(M / 128)
+int conv3_patch_tn_launch(const void* x, const void* w_packed, const float* bias, void* y, float* stat_sum, float* stat_sq,
+                          int n_img, int H, int W, int Cin, int Cout, double flops, double bytes, hipStream_t s) {
+    PatchTN p = {};
+    p.A = (const bf16_t*)x; p.B = (const bf16_t*)w_packed; p.bias = bias; p.out = (bf16_t*)y;
+    p.stat_sum = stat_sum; p.stat_sq = stat_sq;
+    p.M = n_img * H * W; p.N = Cout; p.C = Cin; p.H = H; p.wshift = pt_ilog2(W);
+    const long hw = (long)H * W;
+    if (hw >= 128) { p.G = 1; p.R = 128 / W; } else { p.G = (int)(128 / hw); p.R = H; }
+    p.rwshift = pt_ilog2(p.R * W);
+    p.PR = p.G * (p.R + 2) * (W + 2);
+    VAE_CHECK(p.PR <= PT_ROWS_MAX && p.rwshift >= 0, "conv3 patch kernel: internal geometry error (PR=%d)", p.PR);
+    const int bn = Cout % 128 == 0 ? 128 : 64;
+    dim3 grid((p.M + PT_BM - 1) / PT_BM, Cout / bn);
+    static char name[2][48] = {"conv3_patch_tn_kernel<64>", "conv3_patch_tn_kernel<128>"};
+    ProfScope prof(name[bn == 128], flops, bytes, s);
+    switch (W) {
+        case 4: pt_launch_w<4>(p, grid, bn, s); break;
+        case 8: pt_launch_w<8>(p, grid, bn, s); break;
+        case 16: pt_launch_w<16>(p, grid, bn, s); break;
+        case 32: pt_launch_w<32>(p, grid, bn, s); break;
+        default: pt_launch_w<64>(p, grid, bn, s); break;
+    }
+    VAE_LAUNCH_CHECK("conv3_patch_tn_kernel");
+    return 0;
+}
+
+}  // namespace vae

@@ -7,13 +7,20 @@
 // tile's pixels plus a one-pixel halo, zero where the halo leaves the image (<= 25 KB), instead of
 // nine shifted copies of the tile -- 5.6x fewer bytes through L2/LDS per FLOP than one tap per
 // workgroup, and dY is read once instead of nine times.  The nine taps are then nine row-shifted
-// transposing reads (ds_read_b64_tr_b16) of the same patch.  Each wave owns 16 input channels x all 64 output
-// channels x 9 taps (36 MFMA tiles, 144 VGPRs), so the dY fragments are read once per 9 taps.  K is split over gridDim.z into slabs [split][co][tap][ci] exactly like the
-// one-tap kernel, so the same reducer folds them.
+// transposing reads (ds_read_b64_tr_b16) of the same patch.  Each wave owns 16 input channels x
+// all 64 output channels x 9 taps (36 MFMA tiles, 144 VGPRs), so the dY fragments are read once
+// per 9 taps.  K is split over gridDim.z into slabs [split][co][tap][ci] exactly like the one-tap
+// kernel, so the same reducer folds them.
 //
 // Geometry: a K tile is 64 consecutive pixels = G groups of R image rows (R*W*G = 64); with
 // H*W >= 64 that is one group of 64/W rows of one image, for smaller images 64/(H*W) whole images.
 // Patch row of pixel (g, r, x), r in [-1, R], x in [-1, W]:  (g*(R+2) + r+1)*(W+2) + x+1.
+//
+// The bank swizzle of the patch is a function of the patch COLUMN (x+1) only, and the image width
+// is a template parameter: a vertical tap shift is then a compile-time byte offset on the same
+// address register (the swizzle does not change), a horizontal shift picks one of three
+// precomputed addresses.  12 address registers serve the 36 shifted reads of a K tile, which
+// leaves room to keep the next tap's fragment in flight while the current one feeds the MFMAs.
 #include "common.h"
 #include "prof.h"
 #include "../../include/vae_hip.h"
@@ -29,7 +36,7 @@ struct PatchP {
     const bf16_t* Q;   // X  [Ktot][Ci]
     float* slab;
     int Co, Ci, Ktot;
-    int H, W, wshift;
+    int H, wshift;
     int R, G, rwshift;     // rows per group, groups per tile, log2(R*W)
     int PR;                // patch rows
     int ktiles, kps;       // K tiles in total / per split
@@ -40,25 +47,23 @@ constexpr int PATCH_ROWS_MAX = 200;                   // >= 3*(64+2) = 198, mult
 constexpr int PATCH_INSTR_PER_WAVE = (PATCH_ROWS_MAX / 8 + 3) / 4;   // 7
 constexpr int ROWB = 128;                             // 64 channels of bf16
 
-__device__ __forceinline__ int swz128(int row) { return (((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1; }
+// XOR applied to the 16-byte chunk index of a 128-byte LDS row; `i` is the row index (dY tile) or
+// the patch column (input patch).  One transposing read touches, per 32-lane half, rows/columns
+// {b..b+3} and {b+8..b+11}: bit 0 picks the 128-byte half of the bank line by itself, bits 1 and 3
+// spread the rest over the four 32-byte slots.
+__device__ __forceinline__ int swz128(int i) { return (((i >> 1) & 1) | (((i >> 3) & 1) << 1)) << 1; }
 
-// transposing fragment: lanes 16g..16g+15 take rows row_lo + (t>>2) and row_hi + (t>>2) (4 each) of
-// columns col0..col0+15; lane (l & 15) ends up with 8 consecutive k of column col0 + (l & 15)
-__device__ __forceinline__ bf16x8 tr_frag2(const unsigned char* base, int row_lo, int row_hi, int col0, int lane) {
-    const int t = lane & 15;
-    const int off = (col0 + 4 * (t & 3)) * 2;
-    const int chunk = off >> 4, within = off & 15;
-    const int ra = row_lo + (t >> 2), rb = row_hi + (t >> 2);
-    const unsigned char* a = base + ra * ROWB + (((chunk ^ swz128(ra)) << 4) | within);
-    const unsigned char* b = base + rb * ROWB + (((chunk ^ swz128(rb)) << 4) | within);
-    const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((l4ptr_t)(a));
-    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((l4ptr_t)(b));
+__device__ __forceinline__ bf16x8 tr_pair(const unsigned char* lo_addr, const unsigned char* hi_addr) {
+    const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((l4ptr_t)(lo_addr));
+    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((l4ptr_t)(hi_addr));
     typedef __attribute__((ext_vector_type(8))) short short8v;
     const short8v v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_bit_cast(bf16x8, v);
 }
 
+template <int W>
 __global__ __launch_bounds__(256, 2) void conv3_wgrad_patch_kernel(const PatchP p) {
+    constexpr int W2 = W + 2;
     constexpr int P_BYTES = 64 * ROWB, Q_BYTES = PATCH_ROWS_MAX * ROWB, STAGE = P_BYTES + Q_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
 
@@ -66,7 +71,6 @@ __global__ __launch_bounds__(256, 2) void conv3_wgrad_patch_kernel(const PatchP 
     const int n0 = blockIdx.x * 64, m0 = blockIdx.y * 64, split = blockIdx.z;
     const int kt_beg = split * p.kps, kt_end = min(kt_beg + p.kps, p.ktiles);
     const bf16_t* zero = (const bf16_t*)g_zero_page;
-    const int W2 = p.W + 2;
 
     // ---- per-lane patch staging state (the lane's patch rows never change) -------------
     // packed: bits 0-7 pixel offset inside the tile + 128, 8-15 image-row offset r + 1, 16-18 source chunk,
@@ -76,13 +80,11 @@ __global__ __launch_bounds__(256, 2) void conv3_wgrad_patch_kernel(const PatchP 
 #pragma unroll
     for (int i = 0; i < PATCH_INSTR_PER_WAVE; ++i) {
         const int prow = (wave + 4 * i) * 8 + (lane >> 3);
-        int st = ((lane & 7) ^ swz128(prow)) << 16;
-        if (prow < p.PR) {
-            const int per = (p.R + 2) * W2;
-            const int g = prow / per, rem = prow - g * per;
-            const int rr = rem / W2, xx = rem - rr * W2;
-            if (xx >= 1 && xx <= p.W) st |= ((g * p.R + (rr - 1)) * p.W + (xx - 1) + 128) | (rr << 8) | (1 << 24);
-        }
+        const int per = (p.R + 2) * W2;
+        const int g = prow / per, rem = prow - g * per;
+        const int rr = rem / W2, xx = rem - rr * W2;
+        int st = ((lane & 7) ^ swz128(xx)) << 16;
+        if (prow < p.PR && xx >= 1 && xx <= W) st |= ((g * p.R + (rr - 1)) * W + (xx - 1) + 128) | (rr << 8) | (1 << 24);
         q_st[i] = st;
     }
     const int p_row0 = wave * 8 + (lane >> 3);
@@ -94,13 +96,12 @@ __global__ __launch_bounds__(256, 2) void conv3_wgrad_patch_kernel(const PatchP 
         const int k0 = kt * 64;
         {
             int ra = p_row0, ca = p_ch0;
-            asm volatile("" : "+v"(ra), "+v"(ca));
-            const int ka = k0 + ra, kb = ka + 32;
-            const int cb = ca;                // rows 32 apart agree in both swizzle bits
+            asm volatile("" : "+v"(ra), "+v"(ca));      // keep the address math inside the loop (registers are scarce here)
+            const int ka = k0 + ra, kb = ka + 32;       // rows 32 apart agree in both swizzle bits
             const unsigned char* pcol = (const unsigned char*)(p.P + m0);
             const unsigned prow = (unsigned)p.Co * 2;
             const unsigned char* sa = ka < p.Ktot ? pcol + ((unsigned)ka * prow + ca * 16) : (const unsigned char*)zero;
-            const unsigned char* sb = kb < p.Ktot ? pcol + ((unsigned)kb * prow + cb * 16) : (const unsigned char*)zero;
+            const unsigned char* sb = kb < p.Ktot ? pcol + ((unsigned)kb * prow + ca * 16) : (const unsigned char*)zero;
             __builtin_amdgcn_global_load_lds((gptr_t)sa, (lptr_t)(pbase + wave * 1024), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gptr_t)sb, (lptr_t)(pbase + (wave + 4) * 1024), 16, 0, 0);
         }
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(256, 2) void conv3_wgrad_patch_kernel(const PatchP 
             if (wave + 4 * i < ninstr) {     // wave-uniform
                 const unsigned char* src = (const unsigned char*)zero;
                 int st = q_st[i];
-                asm volatile("" : "+v"(st));      // keep the unpacking inside the loop (registers are scarce here)
+                asm volatile("" : "+v"(st));
                 const int k = k0 + (st & 255) - 128, r = ((st >> 8) & 255) - 1;
                 if ((st >> 24) && (unsigned)(h0 + r) < (unsigned)p.H && (unsigned)k < (unsigned)p.Ktot)
                     src = qcol + ((unsigned)k * rowb + ((st >> 12) & 0x70));
@@ -127,11 +128,33 @@ __global__ __launch_bounds__(256, 2) void conv3_wgrad_patch_kernel(const PatchP 
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // patch row of tile pixel k (k % 4 == 0)
-    auto prow_of = [&](int k) {
-        const int g = k >> p.rwshift, kr = k & ((1 << p.rwshift) - 1);
-        const int r = kr >> p.wshift, x = kr & (p.W - 1);
-        return (g * (p.R + 2) + r + 1) * W2 + x + 1;
+    // ---- per-lane fragment addresses (byte offsets inside a stage) ----------------------
+    // lanes 16g..16g+15 own pixels kk*32 + 8g .. +7 of the tile: quad `lo` = the first four, `hi` = the
+    // last four; lane t of the group reads pixel (t >> 2) of the quad, channels 4(t & 3).. of the fragment.
+    const int t16 = lane & 15;
+    int q_addr[2][2][3];       // [kk][lo/hi][dw + 1], tap row dh = -1; (dh + 1) * W2 * ROWB is added as an immediate
+    int p_addr[2][2];          // [kk][lo/hi] for output-channel fragment j = 0; fragment j flips chunk bits 1-2
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int hl = 0; hl < 2; ++hl) {
+            const int k = kk * 32 + 8 * (lane >> 4) + 4 * hl;             // first pixel of the quad
+            const int g = k >> p.rwshift, kr = k & ((1 << p.rwshift) - 1);
+            const int r = kr >> p.wshift, x = (kr & (W - 1)) + (t16 >> 2);
+            const int prow = (g * (p.R + 2) + r) * W2 + x + 1;            // patch row of the pixel one image row up
+            const int chunk = wave * 2 + ((t16 & 3) >> 1), within = (t16 & 1) * 8;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const int xx = x + d;                                    // patch column of the pixel shifted by dw = d - 1
+                q_addr[kk][hl][d] = P_BYTES + (prow + d - 1) * ROWB + (((chunk ^ swz128(xx)) << 4) | within);
+            }
+            const int row = k + (t16 >> 2);
+            p_addr[kk][hl] = row * ROWB + (((((t16 & 3) >> 1)) ^ swz128(row)) << 4 | within);
+        }
+
+    auto q_frag = [&](const unsigned char* sbase, int kk, int t) -> bf16x8 {
+        const int dh = t / 3, dw = t % 3;      // 0..2
+        return tr_pair(sbase + q_addr[kk][0][dw] + dh * W2 * ROWB, sbase + q_addr[kk][1][dw] + dh * W2 * ROWB);
     };
 
     if (kt_beg < kt_end) stage(0, kt_beg);
@@ -139,22 +162,27 @@ __global__ __launch_bounds__(256, 2) void conv3_wgrad_patch_kernel(const PatchP 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (kt + 1 < kt_end) stage((kt + 1 - kt_beg) & 1, kt + 1);
-        const unsigned char* pbase = smem + ((kt - kt_beg) & 1) * STAGE;
-        const unsigned char* qbase = pbase + P_BYTES;
+        const unsigned char* sbase = smem + ((kt - kt_beg) & 1) * STAGE;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            const int kq = kk * 32 + 8 * (lane >> 4);          // this lane group's 8 pixels
             bf16x8 pb[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) pb[j] = tr_frag2(pbase, kq, kq + 4, j * 16, lane);
-            const int r_lo = prow_of(kq), r_hi = prow_of(kq + 4);
+            for (int j = 0; j < 4; ++j) {
+                int alo = p_addr[kk][0], ahi = p_addr[kk][1];
+                if (j) {   // the XOR stays in the loop: four address registers instead of sixteen
+                    asm volatile("v_xor_b32 %0, %1, %2" : "=v"(alo) : "n"(j << 5), "v"(p_addr[kk][0]));
+                    asm volatile("v_xor_b32 %0, %1, %2" : "=v"(ahi) : "n"(j << 5), "v"(p_addr[kk][1]));
+                }
+                pb[j] = tr_pair(sbase + alo, sbase + ahi);
+            }
+            bf16x8 qa[2];
+            qa[0] = q_frag(sbase, kk, 0);
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
-                const int sh = (t / 3 - 1) * W2 + (t % 3 - 1);
-                const bf16x8 qa = tr_frag2(qbase, r_lo + sh, r_hi + sh, wave * 16, lane);
+                if (t + 1 < 9) qa[(t + 1) & 1] = q_frag(sbase, kk, t + 1);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, pb[j], acc[t][j], 0, 0, 0);
+                    acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[t & 1], pb[j], acc[t][j], 0, 0, 0);
             }
         }
     }
@@ -195,10 +223,10 @@ extern "C" int vae_conv3_wgrad_patch_ok(int H, int W, int Cin, int Cout) {
 extern "C" int vae_conv3_wgrad_patch_ksplit(int n_img, int H, int W, int Cin, int Cout) {
     const long ktiles = ((long)n_img * H * W + 63) / 64;
     const long tiles = (long)(Cin / 64) * (Cout / 64);
-    long s = (256 + tiles - 1) / tiles;
+    long s = (512 + tiles - 1) / tiles;          // two workgroups per CU
     const long maxs = ktiles / 4 > 0 ? ktiles / 4 : 1;
     if (s > maxs) s = maxs;
-    if (s > 256) s = 256;
+    if (s > 512) s = 512;
     if (s < 1) s = 1;
     const long kps = (ktiles + s - 1) / s;
     return (int)((ktiles + kps - 1) / kps);
@@ -214,7 +242,7 @@ extern "C" int vae_conv3_wgrad_patch(const void* dy, const void* x, float* slab,
     PatchP p = {};
     p.P = (const bf16_t*)dy; p.Q = (const bf16_t*)x; p.slab = slab;
     p.Co = Cout; p.Ci = Cin; p.Ktot = n_img * H * W;
-    p.H = H; p.W = W; p.wshift = ilog2x(W);
+    p.H = H; p.wshift = ilog2x(W);
     const long hw = (long)H * W;
     if (hw >= 64) { p.G = 1; p.R = 64 / W; } else { p.G = (int)(64 / hw); p.R = H; }
     p.rwshift = ilog2x(p.R * W);
@@ -230,7 +258,13 @@ extern "C" int vae_conv3_wgrad_patch(const void* dy, const void* x, float* slab,
     const double flops = 2.0 * Cout * Cin * 9.0 * p.Ktot;
     const double bytes = 2.0 * p.Ktot * ((double)Cout + Cin) + 4.0 * nsplit * 9.0 * Cout * Cin;
     ProfScope prof("conv3_wgrad_patch_kernel", flops, bytes, s);
-    hipLaunchKernelGGL(conv3_wgrad_patch_kernel, grid, dim3(256), 0, s, p);
+    switch (W) {
+        case 4: hipLaunchKernelGGL(conv3_wgrad_patch_kernel<4>, grid, dim3(256), 0, s, p); break;
+        case 8: hipLaunchKernelGGL(conv3_wgrad_patch_kernel<8>, grid, dim3(256), 0, s, p); break;
+        case 16: hipLaunchKernelGGL(conv3_wgrad_patch_kernel<16>, grid, dim3(256), 0, s, p); break;
+        case 32: hipLaunchKernelGGL(conv3_wgrad_patch_kernel<32>, grid, dim3(256), 0, s, p); break;
+        default: hipLaunchKernelGGL(conv3_wgrad_patch_kernel<64>, grid, dim3(256), 0, s, p); break;
+    }
     VAE_LAUNCH_CHECK("conv3_wgrad_patch_kernel");
     return 0;
 }

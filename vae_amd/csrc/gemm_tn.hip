@@ -26,6 +26,11 @@
 
 namespace vae {
 
+// conv3_patch_tn.hip
+bool conv3_patch_tn_ok(int n_img, int H, int W, int Cin, int Cout);
+int conv3_patch_tn_launch(const void* x, const void* w_packed, const float* bias, void* y, float* stat_sum, float* stat_sq,
+                          int n_img, int H, int W, int Cin, int Cout, double flops, double bytes, hipStream_t s);
+
 enum { A_PLAIN = 0, A_CONV3 = 1, A_CONVT_DGRAD = 2, A_CONV3_C8 = 3 };
 enum { E_BF16 = 0, E_CONVT = 1, E_F32_SPLIT = 2, E_TANH_BF16 = 3, E_F32 = 4 };
 
@@ -187,29 +192,33 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
     for (int ks = 0; ks < nk; ++ks) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (ks + 1 < nk) stage((ks + 1) & 1, ks + 1);
         const unsigned char* abase = smem + (ks & 1) * STAGE;
         const unsigned char* bbase = abase + A_BYTES;
+        // all fragments of this K-step are requested up front, the next tile's global->LDS copies are
+        // issued while they are in flight, then the matrix instructions drain them in order
+        bf16x8 xa[BK / 32][FM], wb[BK / 32][FN];
 #pragma unroll
         for (int kk = 0; kk < BK / 32; ++kk) {
-            bf16x8 xa[FM], wb[FN];
             const int chunk = kk * 4 + (lane >> 4);
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
                 const int row = wm * TM + i * 16 + (lane & 15);
-                xa[i] = *(const bf16x8*)(abase + row * ROWB + ((chunk ^ ((row >> SW) & (CH - 1))) << 4));
+                xa[kk][i] = *(const bf16x8*)(abase + row * ROWB + ((chunk ^ ((row >> SW) & (CH - 1))) << 4));
             }
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
                 const int row = wn * TN + j * 16 + (lane & 15);
-                wb[j] = *(const bf16x8*)(bbase + row * ROWB + ((chunk ^ ((row >> SW) & (CH - 1))) << 4));
+                wb[kk][j] = *(const bf16x8*)(bbase + row * ROWB + ((chunk ^ ((row >> SW) & (CH - 1))) << 4));
             }
+        }
+        if (ks + 1 < nk) stage((ks + 1) & 1, ks + 1);
+#pragma unroll
+        for (int kk = 0; kk < BK / 32; ++kk)
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int j = 0; j < FN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
-        }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[kk][j], xa[kk][i], acc[i][j], 0, 0, 0);
     }
 
     // ---- epilogue ----------------------------------------------------------------------
@@ -371,6 +380,10 @@ extern "C" int vae_conv3x3_gemm(const void* x, const void* w_packed, const float
     p.flops = 2.0 * p.M * p.N * p.K;
     p.bytes = 2.0 * ((double)p.M * Cin + (double)p.N * p.K + (double)p.M * Cout);
     if (int e = check_common(p, 64, "vae_conv3x3_gemm")) return e;
+    // big layers on power-of-two images: the patch-staged kernel (conv3_patch_tn.hip); same tile height, same statistics rows
+    if (pick_bm(p.M, p.N) == 128 && conv3_patch_tn_ok(n_img, H, W, Cin, Cout))
+        return conv3_patch_tn_launch(x, w_packed, bias, y, stat_sum, stat_sq, n_img, H, W, Cin, Cout, p.flops, p.bytes,
+                                     (hipStream_t)stream);
     return launch_bk64<A_CONV3, E_BF16>(p, (hipStream_t)stream);
 }
 
