@@ -40,6 +40,7 @@ struct PatchTN {
     int H, wshift;
     int R, G, rwshift;    // rows per group, groups per tile, log2(R*W)
     int PR;               // patch rows
+    float inv_per;        // 1 / ((R + 2) * (W + 2))
 };
 
 constexpr int PT_BM = 128;
@@ -69,7 +70,8 @@ __global__ __launch_bounds__(256, 2) void conv3_patch_tn_kernel(const PatchTN p)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int m0 = blockIdx.x * PT_BM, n0 = blockIdx.y * BN;
+    const int n0 = blockIdx.y * BN;
+    int m0 = 0, h0 = 0;          // first pixel of the current tile and its image row (set per tile below)
     const bf16_t* zero = (const bf16_t*)g_zero_page;
     const int K = 9 * p.C;
 
@@ -81,14 +83,15 @@ __global__ __launch_bounds__(256, 2) void conv3_patch_tn_kernel(const PatchTN p)
 #pragma unroll
     for (int i = 0; i < PT_Q_INSTR; ++i) {
         const int prow = (wave + 4 * i) * 8 + (lane >> 3);
+        // patch row -> (group, image row, column); exact float reciprocal division (operands < 2^9)
         const int per = (p.R + 2) * W2;
-        const int g = prow / per, rem = prow - g * per;
-        const int rr = rem / W2, xx = rem - rr * W2;
+        const int g = p.G == 1 ? 0 : (int)(((float)prow + 0.5f) * p.inv_per);
+        const int rem = prow - g * per;
+        const int rr = (int)(((float)rem + 0.5f) * (1.0f / W2)), xx = rem - rr * W2;
         int st = ((lane & 7) ^ ((xx >> 1) & 7)) << 18;
         if (prow < p.PR && xx >= 1 && xx <= W) st |= ((g * p.R + (rr - 1)) * W + (xx - 1) + 256) | (rr << 10) | (1 << 24);
         q_st[i] = st;
     }
-    const int h0 = p.G == 1 ? ((m0 >> p.wshift) & (p.H - 1)) : 0;
     const unsigned rowb = (unsigned)p.C * 2;
 
     auto stage_patch = [&](int c0) {
@@ -147,16 +150,22 @@ __global__ __launch_bounds__(256, 2) void conv3_patch_tn_kernel(const PatchTN p)
             b_addr[j][kk] = Q_BYTES + row * PT_ROWB + (((kk * 4 + (lane >> 4)) ^ ((row >> 1) & 7)) << 4);
     }
 
+    // ---- persistent loop over pixel tiles: the address tables above are computed once per workgroup ----
+    const int nchunk = p.C / 64;
+    const int ntiles = (p.M + PT_BM - 1) / PT_BM;
+    int par = 0;                                   // weight buffer holding the current tap
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    if (tile != (int)blockIdx.x) __syncthreads();  // the statistics scratch of the previous tile has been read
+    m0 = tile * PT_BM;
+    h0 = p.G == 1 ? ((m0 >> p.wshift) & (p.H - 1)) : 0;
     f32x4 acc[FM][FN];
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nchunk = p.C / 64;
     stage_patch(0);
-    stage_b(0, 0);
-    int par = 0;                                   // weight buffer holding the current tap
+    stage_b(par, 0);
     for (int c = 0; c < nchunk; ++c) {
         const int c0 = c * 64;
 #pragma unroll
@@ -241,10 +250,11 @@ __global__ __launch_bounds__(256, 2) void conv3_patch_tn_kernel(const PatchTN p)
             float s = 0.f, q = 0.f;
 #pragma unroll
             for (int w = 0; w < WAVES_M; ++w) { s += red[w * BN + tid]; q += red[(WAVES_M + w) * BN + tid]; }
-            p.stat_sum[(long)blockIdx.x * p.N + n0 + tid] = s;
-            p.stat_sq[(long)blockIdx.x * p.N + n0 + tid] = q;
+            p.stat_sum[(long)tile * p.N + n0 + tid] = s;
+            p.stat_sq[(long)tile * p.N + n0 + tid] = q;
         }
     }
+    }   // tile loop
 }
 
 static int pt_ilog2(int v) {
@@ -283,9 +293,14 @@ int conv3_patch_tn_launch(const void* x, const void* w_packed, const float* bias
     if (hw >= 128) { p.G = 1; p.R = 128 / W; } else { p.G = (int)(128 / hw); p.R = H; }
     p.rwshift = pt_ilog2(p.R * W);
     p.PR = p.G * (p.R + 2) * (W + 2);
+    p.inv_per = 1.0f / (float)((p.R + 2) * (W + 2));
     VAE_CHECK(p.PR <= PT_ROWS_MAX && p.rwshift >= 0, "conv3 patch kernel: internal geometry error (PR=%d)", p.PR);
     const int bn = Cout % 128 == 0 ? 128 : 64;
-    dim3 grid((p.M + PT_BM - 1) / PT_BM, Cout / bn);
+    const int ntiles = (p.M + PT_BM - 1) / PT_BM, gy = Cout / bn;
+    int gx = 512 / gy;                       // two resident workgroups per CU, each walking ntiles / gx tiles
+    if (gx > ntiles) gx = ntiles;
+    if (gx < 1) gx = 1;
+    dim3 grid(gx, gy);
     static char name[2][48] = {"conv3_patch_tn_kernel<64>", "conv3_patch_tn_kernel<128>"};
     ProfScope prof(name[bn == 128], flops, bytes, s);
     switch (W) {

@@ -49,6 +49,7 @@ struct GemmTN {
     int split;            // E_F32_SPLIT: columns per half
     int Co;               // E_CONVT: channels per tap
     int wshift, hshift;   // log2(W), log2(H) when both are powers of two, else -1
+    unsigned a_bytes, b_bytes;   // sizes of A and B in bytes (buffer descriptors; both < 4 GiB)
     double flops, bytes;  // algorithmic work of this launch (profiling only)
 };
 
@@ -80,7 +81,18 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
-template <int BM, int BN, int BK, int WAVES_M, int AMODE, int EPI>
+// s_waitcnt vmcnt(n) for a wave-uniform runtime n in [0, 3 * per]: at most n global->LDS copies stay in flight
+template <int PER>
+__device__ __forceinline__ void wait_vm_groups(int groups) {
+    if (groups <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (groups == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+    else if (groups == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PER) : "memory");
+}
+
+// NST-deep ring of LDS stages: the copies of K-step ks + NST - 1 are issued while K-step ks computes, so a
+// tile has NST - 1 K-steps of compute to arrive (one K-step is shorter than an L2 round trip).
+template <int BM, int BN, int BK, int WAVES_M, int AMODE, int EPI, int NST>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
     constexpr int WAVES_N = 4 / WAVES_M;
     constexpr int TM = BM / WAVES_M, TN = BN / WAVES_N;
@@ -92,92 +104,101 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
     constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
     constexpr int A_INSTR = BM / RPI / 4, B_INSTR = BN / RPI / 4;
     static_assert(FM >= 1 && FN >= 1 && A_INSTR >= 1 && B_INSTR >= 1, "tile too small");
-    static_assert(2 * STAGE >= (int)(2 * WAVES_M * BN * sizeof(float)), "stats scratch does not fit");
+    static_assert(NST >= 2 && NST <= 5, "ring depth");
+    static_assert(NST * STAGE >= (int)(2 * WAVES_M * BN * sizeof(float)), "stats scratch does not fit");
+    static_assert((NST - 2) * 3 * (A_INSTR + B_INSTR) <= 63 || NST <= 4, "vmcnt range");
 
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NST * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
 
     // ---- per-lane staging state ------------------------------------------------------
-    const bf16_t* zero = (const bf16_t*)g_zero_page;
-    long a_off[A_INSTR];
+    // Tiles are fetched with buffer_load ... lds: a 32-bit byte offset per lane against a buffer
+    // descriptor held in SGPRs.  An offset past the buffer (OOB below) makes the hardware deliver
+    // zeros, which is how padding pixels and rows past M / N are filled -- no pointer select, no
+    // 64-bit address arithmetic in the loop.
+    constexpr unsigned OOB = 0xFFFFFFFFu;
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)p.b_bytes, 0x00020000);
+    unsigned a_off[A_INSTR];   // byte offset of this lane's 16-byte chunk at K = 0 (OOB: row >= M)
     int a_hw[A_INSTR];
     int a_chunk[A_INSTR];
-    bool a_ok[A_INSTR];
 #pragma unroll
     for (int i = 0; i < A_INSTR; ++i) {
         const int row = (wave + 4 * i) * RPI + lane / CH;
         const int chunk = (lane % CH) ^ ((row >> SW) & (CH - 1));
         const int m = m0 + row;
-        a_ok[i] = m < p.M;
         a_hw[i] = 0;
         a_chunk[i] = chunk;
         int w, h, img;
         split_px(p, m, w, h, img);
+        unsigned off;
         if (AMODE == A_CONV3_C8) {
-            a_off[i] = (long)m * 8;
+            off = (unsigned)m * 16u;
             a_hw[i] = (h << 16) | w;
         } else if (AMODE == A_PLAIN) {
-            a_off[i] = (long)m * p.lda + chunk * 8;
+            off = ((unsigned)m * (unsigned)p.lda + chunk * 8) * 2u;
         } else if (AMODE == A_CONV3) {
-            a_off[i] = (long)m * p.C + chunk * 8;
+            off = ((unsigned)m * (unsigned)p.C + chunk * 8) * 2u;
             a_hw[i] = (h << 16) | w;
         } else {
-            a_off[i] = (((long)img * 2 * p.H + 2 * h) * (2 * p.W) + 2 * w) * p.C + chunk * 8;
+            off = ((((unsigned)img * 2 * p.H + 2 * h) * (2 * p.W) + 2 * w) * (unsigned)p.C + chunk * 8) * 2u;
+        }
+        a_off[i] = m < p.M ? off : OOB;
+        if (AMODE == A_CONV3 || AMODE == A_CONV3_C8) {
+            if (m >= p.M) a_hw[i] = 0x7FFF7FFF;     // fails every bounds test below
         }
     }
-    long b_off[B_INSTR];
-    bool b_ok[B_INSTR];
+    unsigned b_off[B_INSTR];
 #pragma unroll
     for (int i = 0; i < B_INSTR; ++i) {
         const int row = (wave + 4 * i) * RPI + lane / CH;
         const int chunk = (lane % CH) ^ ((row >> SW) & (CH - 1));
         const int n = n0 + row;
-        b_ok[i] = n < p.N;
-        b_off[i] = (long)n * p.K + chunk * 8;
+        b_off[i] = n < p.N ? ((unsigned)n * (unsigned)p.K + chunk * 8) * 2u : OOB;
     }
     const int cpt = (AMODE == A_PLAIN || AMODE == A_CONV3_C8) ? 1 : p.C / BK;   // K-steps per tap
 
     auto stage = [&](int buf, int ks) {
         unsigned char* abase = smem + buf * STAGE;
-        long tap_off = 0;
+        int tap_off = 0;      // bytes
         int dh = 0, dw = 0;
         if (AMODE == A_PLAIN) {
-            tap_off = (long)ks * BK;
+            tap_off = ks * BK * 2;
         } else if (AMODE == A_CONV3_C8) {
             tap_off = 0;
         } else if (AMODE == A_CONV3) {
             const int tap = ks / cpt, c0 = (ks - tap * cpt) * BK;
             dh = tap / 3 - 1;
             dw = tap % 3 - 1;
-            tap_off = ((long)dh * p.W + dw) * p.C + c0;
+            tap_off = ((dh * p.W + dw) * p.C + c0) * 2;
         } else {
             const int tap = ks / cpt, c0 = (ks - tap * cpt) * BK;
-            tap_off = ((long)(tap >> 1) * 2 * p.W + (tap & 1)) * p.C + c0;
+            tap_off = (((tap >> 1) * 2 * p.W + (tap & 1)) * p.C + c0) * 2;
         }
 #pragma unroll
         for (int i = 0; i < A_INSTR; ++i) {
-            bool ok = a_ok[i];
+            unsigned off = a_off[i] == OOB ? OOB : a_off[i] + (unsigned)tap_off;
             if (AMODE == A_CONV3) {
                 const int h = (a_hw[i] >> 16) + dh, w = (a_hw[i] & 0xFFFF) + dw;
-                ok = ok && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
+                if (!((unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W)) off = OOB;
             }
             if (AMODE == A_CONV3_C8) {
                 const int tp = ks * 8 + a_chunk[i];
                 const int eh = tp / 3 - 1, ew = tp % 3 - 1;
                 const int h = (a_hw[i] >> 16) + eh, w = (a_hw[i] & 0xFFFF) + ew;
-                ok = ok && tp < 9 && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
-                tap_off = ((long)eh * p.W + ew) * 8;
+                off = (tp < 9 && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W)
+                          ? a_off[i] + (unsigned)((eh * p.W + ew) * 16) : OOB;
             }
-            const bf16_t* src = ok ? p.A + a_off[i] + tap_off : zero;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(abase + (wave + 4 * i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lptr_t)(abase + (wave + 4 * i) * 1024), 16, (int)off, 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < B_INSTR; ++i) {
-            const bf16_t* src = b_ok[i] ? p.B + b_off[i] + (long)ks * BK : zero;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(abase + A_BYTES + (wave + 4 * i) * 1024), 16, 0, 0);
+            const unsigned off = b_off[i] == OOB ? OOB : b_off[i] + (unsigned)(ks * BK * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (lptr_t)(abase + A_BYTES + (wave + 4 * i) * 1024), 16, (int)off, 0, 0,
+                                                     0);
         }
     };
 
@@ -188,11 +209,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
         for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nk = p.K / BK;
-    stage(0, 0);
+#pragma unroll
+    for (int q = 0; q < NST - 1; ++q)
+        if (q < nk) stage(q, q);
+    int slot = 0;                     // ring slot of K-step ks
     for (int ks = 0; ks < nk; ++ks) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wait_vm_groups<A_INSTR + B_INSTR>(min(NST - 2, nk - 1 - ks));   // everything up to K-step ks has landed
         __syncthreads();
-        const unsigned char* abase = smem + (ks & 1) * STAGE;
+        const unsigned char* abase = smem + slot * STAGE;
         const unsigned char* bbase = abase + A_BYTES;
         // all fragments of this K-step are requested up front, the next tile's global->LDS copies are
         // issued while they are in flight, then the matrix instructions drain them in order
@@ -211,7 +235,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
                 wb[kk][j] = *(const bf16x8*)(bbase + row * ROWB + ((chunk ^ ((row >> SW) & (CH - 1))) << 4));
             }
         }
-        if (ks + 1 < nk) stage((ks + 1) & 1, ks + 1);
+        if (ks + NST - 1 < nk) stage(slot == 0 ? NST - 1 : slot - 1, ks + NST - 1);   // the slot read in K-step ks - 1
+        slot = slot + 1 == NST ? 0 : slot + 1;
 #pragma unroll
         for (int kk = 0; kk < BK / 32; ++kk)
 #pragma unroll
@@ -309,11 +334,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
 
 template <int BM, int BN, int BK, int WAVES_M, int AMODE, int EPI>
 static int launch_one(const GemmTN& p, hipStream_t s) {
+    // ring depth: as deep as lets two workgroups share a CU's 160 KB of LDS
+    constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
+    constexpr int NST = STAGE_BYTES <= 16384 ? 4 : STAGE_BYTES <= 24576 ? 3 : 2;
     dim3 grid((p.M + BM - 1) / BM, (p.N + BN - 1) / BN);
     static char name[64] = "";
     if (!name[0]) snprintf(name, sizeof(name), "gemm_tn_kernel<%d,%d,%d,%d,%d,%d>", BM, BN, BK, WAVES_M, AMODE, EPI);
     ProfScope prof(name, p.flops, p.bytes, s);
-    hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, BK, WAVES_M, AMODE, EPI>), grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, BK, WAVES_M, AMODE, EPI, NST>), grid, dim3(256), 0, s, p);
     VAE_LAUNCH_CHECK("gemm_tn_kernel");
     return 0;
 }
@@ -341,12 +369,22 @@ static int launch_bk64(GemmTN p, hipStream_t s) {
         if (small) return launch_one<64, 64, 64, 2, AMODE, EPI>(p, s);
         return launch_one<128, 64, 64, 4, AMODE, EPI>(p, s);
     }
-    if (small) return launch_one<64, 128, 64, 2, AMODE, EPI>(p, s);
+    if (small) {
+        // still under one workgroup per CU with 64 x 128 tiles: halve the tile width too
+        const long blocks = ((long)(p.M + 63) / 64) * ((p.N + 127) / 128);
+        if (blocks < 256) return launch_one<64, 64, 64, 2, AMODE, EPI>(p, s);
+        return launch_one<64, 128, 64, 2, AMODE, EPI>(p, s);
+    }
     return launch_one<128, 128, 64, 2, AMODE, EPI>(p, s);
 }
 
-static int check_common(const GemmTN& p, int bk, const char* who) {
+// a_elems: bf16 elements in the A operand's buffer (the staging offsets are 32-bit byte offsets into it)
+static int check_common(GemmTN& p, int bk, const char* who, double a_elems) {
     VAE_CHECK(p.A && p.B && p.out, "%s: null pointer", who);
+    const double lim = 4294967296.0 - 64.0;
+    VAE_CHECK(2.0 * a_elems < lim && 2.0 * p.N * (double)p.K < lim, "%s: an operand of 4 GiB or more is not supported", who);
+    p.a_bytes = (unsigned)(2.0 * a_elems);
+    p.b_bytes = (unsigned)(2.0 * p.N * (double)p.K);
     VAE_CHECK(p.M > 0 && p.N > 0 && p.K > 0, "%s: empty problem M=%d N=%d K=%d", who, p.M, p.N, p.K);
     VAE_CHECK(p.K % bk == 0, "%s: K=%d must be a multiple of %d", who, p.K, bk);
     VAE_CHECK(p.N % 4 == 0, "%s: N=%d must be a multiple of 4", who, p.N);
@@ -379,9 +417,9 @@ extern "C" int vae_conv3x3_gemm(const void* x, const void* w_packed, const float
     p.M = n_img * H * W; p.N = Cout; p.K = 9 * Cin; p.H = H; p.W = W; p.C = Cin; p.ldo = Cout;
     p.flops = 2.0 * p.M * p.N * p.K;
     p.bytes = 2.0 * ((double)p.M * Cin + (double)p.N * p.K + (double)p.M * Cout);
-    if (int e = check_common(p, 64, "vae_conv3x3_gemm")) return e;
+    if (int e = check_common(p, 64, "vae_conv3x3_gemm", (double)p.M * Cin)) return e;
     // big layers on power-of-two images: the patch-staged kernel (conv3_patch_tn.hip); same tile height, same statistics rows
-    if (pick_bm(p.M, p.N) == 128 && conv3_patch_tn_ok(n_img, H, W, Cin, Cout))
+    if ((pick_bm(p.M, p.N) == 128 || getenv("VAE_FORCE_PATCH")) && conv3_patch_tn_ok(n_img, H, W, Cin, Cout))
         return conv3_patch_tn_launch(x, w_packed, bias, y, stat_sum, stat_sq, n_img, H, W, Cin, Cout, p.flops, p.bytes,
                                      (hipStream_t)stream);
     return launch_bk64<A_CONV3, E_BF16>(p, (hipStream_t)stream);
@@ -398,7 +436,7 @@ extern "C" int vae_conv3x3_c8_gemm(const void* x8, const void* w_packed, const f
     p.M = n_img * H * W; p.N = Cout; p.K = 128; p.H = H; p.W = W; p.C = 8; p.ldo = Cout;
     p.flops = 2.0 * p.M * p.N * 27.0;      // 3 real input channels x 9 taps
     p.bytes = 2.0 * ((double)p.M * 8 + (double)p.N * p.K + (double)p.M * Cout);
-    if (int e = check_common(p, 64, "vae_conv3x3_c8_gemm")) return e;
+    if (int e = check_common(p, 64, "vae_conv3x3_c8_gemm", (double)p.M * 8)) return e;
     return launch_bk64<A_CONV3_C8, E_BF16>(p, (hipStream_t)stream);
 }
 
@@ -413,7 +451,7 @@ extern "C" int vae_convt2x2_fwd_gemm(const void* x, const void* w_packed, const 
     p.M = n_img * H * W; p.N = 4 * Cout; p.K = Cin; p.lda = Cin; p.H = H; p.W = W; p.Co = Cout;
     p.flops = 2.0 * p.M * p.N * p.K;
     p.bytes = 2.0 * ((double)p.M * Cin + (double)p.N * p.K + (double)p.M * p.N);
-    if (int e = check_common(p, 64, "vae_convt2x2_fwd_gemm")) return e;
+    if (int e = check_common(p, 64, "vae_convt2x2_fwd_gemm", (double)p.M * Cin)) return e;
     return launch_bk64<A_PLAIN, E_CONVT>(p, (hipStream_t)stream);
 }
 
@@ -426,7 +464,7 @@ extern "C" int vae_convt2x2_dgrad_gemm(const void* dy, const void* w_packed, voi
     p.M = n_img * H * W; p.N = Cin; p.K = 4 * Cout; p.H = H; p.W = W; p.C = Cout; p.ldo = Cin;
     p.flops = 2.0 * p.M * p.N * p.K;
     p.bytes = 2.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N);
-    if (int e = check_common(p, 64, "vae_convt2x2_dgrad_gemm")) return e;
+    if (int e = check_common(p, 64, "vae_convt2x2_dgrad_gemm", 4.0 * p.M * Cout)) return e;
     return launch_bk64<A_CONVT_DGRAD, E_BF16>(p, (hipStream_t)stream);
 }
 
@@ -442,11 +480,11 @@ extern "C" int vae_linear_gemm(const void* a, const void* w, const float* bias, 
     hipStream_t s = (hipStream_t)stream;
     if (K % 64 != 0) {
         VAE_CHECK(epilogue == VAE_EPI_BF16, "vae_linear_gemm: K=%d not a multiple of 64 is only supported with the bf16 epilogue", K);
-        if (int e = check_common(p, 32, "vae_linear_gemm")) return e;
+        if (int e = check_common(p, 32, "vae_linear_gemm", (double)M * K)) return e;
         if (N <= 64) return launch_one<128, 64, 32, 4, A_PLAIN, E_BF16>(p, s);
         return launch_one<128, 128, 32, 2, A_PLAIN, E_BF16>(p, s);
     }
-    if (int e = check_common(p, 64, "vae_linear_gemm")) return e;
+    if (int e = check_common(p, 64, "vae_linear_gemm", (double)M * K)) return e;
     switch (epilogue) {
         case VAE_EPI_BF16: return launch_bk64<A_PLAIN, E_BF16>(p, s);
         case VAE_EPI_TANH_BF16: return launch_bk64<A_PLAIN, E_TANH_BF16>(p, s);

@@ -167,10 +167,32 @@ __global__ __launch_bounds__(1024) void sum_partials_kernel(const float* __restr
 }
 
 // ---------------------------------------------------------------------------------------
+static int pow2_shift(int v) {
+    if (v <= 0 || (v & (v - 1))) return -1;
+    int s = 0;
+    while ((1 << s) < v) ++s;
+    return s;
+}
+
 struct ActGeom {
     int n_img, H, W, C;   // full-resolution geometry of y
     int pool;
+    int wsh2, hsh2;       // log2(W/2), log2(H/2) when both are powers of two, else -1
 };
+
+// pooled position -> (img, ho, wo); shifts on power-of-two grids, 32-bit division otherwise
+__device__ __forceinline__ void split_pooled(const ActGeom& g, unsigned pos, int& wo, int& ho, long& img) {
+    if (g.wsh2 >= 0 && g.hsh2 >= 0) {
+        wo = pos & ((g.W >> 1) - 1);
+        ho = (pos >> g.wsh2) & ((g.H >> 1) - 1);
+        img = pos >> (g.wsh2 + g.hsh2);
+    } else {
+        wo = pos % (unsigned)(g.W >> 1);
+        const unsigned t = pos / (unsigned)(g.W >> 1);
+        ho = t % (unsigned)(g.H >> 1);
+        img = t / (unsigned)(g.H >> 1);
+    }
+}
 
 template <bool POOL>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16_t* __restrict__ y, const float* __restrict__ scale,
@@ -178,25 +200,24 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16_t* __restric
                                                          ActGeom g, DropCfg d) {
     const int cgs = g.C >> 3;
     const long npos = POOL ? (long)g.n_img * (g.H >> 1) * (g.W >> 1) : (long)g.n_img * g.H * g.W;
-    const long total = npos * cgs;
-    for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long)gridDim.x * blockDim.x) {
-        const int cg = (int)(id % cgs);
-        const long pos = id / cgs;
-        const int c0 = cg * 8;
-        float sc[8], sh[8];
-        load8f(scale + c0, sc);
-        load8f(shift + c0, sh);
+    // cgs is a power of two dividing 256: a thread keeps its channel group, positions advance by a fixed stride
+    const int cshift = __ffs(cgs) - 1;
+    const int c0 = (threadIdx.x & (cgs - 1)) * 8;
+    float sc[8], sh[8];
+    load8f(scale + c0, sc);
+    load8f(shift + c0, sh);
+    const unsigned pstride = (gridDim.x * 256u) >> cshift;
+    for (unsigned pos = (blockIdx.x * 256u + threadIdx.x) >> cshift; pos < npos; pos += pstride) {
         float o[8];
         bool ps[8], kp[8];
         if (!POOL) {
             float v[8];
-            load8(y + pos * g.C + c0, v);
-            act8(v, sc, sh, d, pos * g.C + c0, o, ps, kp);
+            load8(y + (long)pos * g.C + c0, v);
+            act8(v, sc, sh, d, (long)pos * g.C + c0, o, ps, kp);
         } else {
-            const int wo = (int)(pos % (g.W >> 1));
-            const long t = pos / (g.W >> 1);
-            const int ho = (int)(t % (g.H >> 1));
-            const long img = t / (g.H >> 1);
+            int wo, ho;
+            long img;
+            split_pooled(g, pos, wo, ho, img);
 #pragma unroll
             for (int i = 0; i < 8; ++i) o[i] = -INFINITY;
 #pragma unroll
@@ -209,7 +230,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16_t* __restric
                 for (int i = 0; i < 8; ++i) o[i] = fmaxf(o[i], a[i]);
             }
         }
-        store8(out + pos * g.C + c0, o);
+        store8(out + (long)pos * g.C + c0, o);
     }
 }
 
@@ -224,8 +245,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const bf16_t* __restric
     __shared__ float red[2][256][8];
     const int cgs = g.C >> 3;
     const long npos = POOL ? (long)g.n_img * (g.H >> 1) * (g.W >> 1) : (long)g.n_img * g.H * g.W;
-    const long total = npos * cgs;
-    const int cg = threadIdx.x % cgs;       // fixed per thread: block and grid strides are multiples of cgs
+    const int cshift = __ffs(cgs) - 1;      // cgs is a power of two dividing 256
+    const int cg = threadIdx.x & (cgs - 1); // fixed per thread: block and grid strides are multiples of cgs
     const int c0 = cg * 8;
     float sc[8], sh[8], mu[8], rs[8], c1[8], c2[8];
     load8f(scale + c0, sc);
@@ -242,8 +263,9 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const bf16_t* __restric
 #pragma unroll
     for (int i = 0; i < 8; ++i) a_gx[i] = a_g[i] = 0.f;
 
-    for (long id = (long)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (long)gridDim.x * blockDim.x) {
-        const long pos = id / cgs;
+    const unsigned pstride = (gridDim.x * 256u) >> cshift;
+    for (unsigned up = (blockIdx.x * 256u + threadIdx.x) >> cshift; up < npos; up += pstride) {
+        const long pos = up;
         float gi[8];
         load8(gin + pos * g.C + c0, gi);
         if (!POOL) {
@@ -262,10 +284,9 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const bf16_t* __restric
             }
             if (PASS == 1) store8(dy + pos * g.C + c0, o);
         } else {
-            const int wo = (int)(pos % (g.W >> 1));
-            const long t = pos / (g.W >> 1);
-            const int ho = (int)(t % (g.H >> 1));
-            const long img = t / (g.H >> 1);
+            int wo, ho;
+            long img;
+            split_pooled(g, up, wo, ho, img);
             float v[4][8], a[4][8];
             bool ps[4][8], kp[4][8];
             long pix[4];
@@ -506,6 +527,7 @@ static DropCfg make_drop(double p_drop, const void* mask, unsigned long long see
 
 static int check_geom(const char* who, int n_img, int H, int W, int C, int pool) {
     VAE_CHECK(n_img > 0 && H > 0 && W > 0 && C > 0, "%s: bad geometry n=%d H=%d W=%d C=%d", who, n_img, H, W, C);
+    VAE_CHECK((long)n_img * H * W < (1L << 31), "%s: more than 2^31 pixels", who);
     VAE_CHECK(C % 8 == 0 && 256 % (C / 8) == 0 && C <= 2048, "%s: C=%d must be 8 * a divisor of 256", who, C);
     VAE_CHECK(!pool || (H % 2 == 0 && W % 2 == 0), "%s: pooling needs even H, W (got %dx%d)", who, H, W);
     return 0;
@@ -514,7 +536,8 @@ static int check_geom(const char* who, int n_img, int H, int W, int C, int pool)
 static int elem_grid(long items) {
     long b = (items + 255) / 256;
     if (b < 1) b = 1;
-    if (b > 2048) b = 2048;
+    static const long cap = getenv("VAE_ELEM_GRID") ? atol(getenv("VAE_ELEM_GRID")) : 2048;
+    if (b > cap) b = cap;
     return (int)b;
 }
 
@@ -561,7 +584,7 @@ extern "C" int vae_bn_act_fwd(const void* y, const float* scale, const float* sh
     VAE_CHECK(y && scale && shift && out, "vae_bn_act_fwd: null pointer");
     if (int e = check_geom("vae_bn_act_fwd", n_img, H, W, C, pool)) return e;
     VAE_CHECK(p_drop >= 0.0 && p_drop < 1.0, "vae_bn_act_fwd: p_drop=%f out of [0,1)", p_drop);
-    ActGeom g = {n_img, H, W, C, pool};
+    ActGeom g = {n_img, H, W, C, pool, pow2_shift(W >> 1), pow2_shift(H >> 1)};
     const DropCfg d = make_drop(p_drop, keep_mask, seed, step, stream_id, rank);
     const long items = (long)n_img * H * W / (pool ? 4 : 1) * (C / 8);
     hipStream_t s = (hipStream_t)stream;
@@ -577,7 +600,8 @@ extern "C" int vae_bn_act_bwd_blocks(int n_img, int H, int W, int C, int pool) {
     const long items = (long)n_img * H * W / (pool ? 4 : 1) * (C / 8);
     long b = (items + 255) / 256;
     if (b < 1) b = 1;
-    if (b > 512) b = 512;
+    static const long cap = getenv("VAE_RED_GRID") ? atol(getenv("VAE_RED_GRID")) : 512;
+    if (b > cap) b = cap;
     return (int)b;
 }
 
@@ -587,7 +611,7 @@ extern "C" int vae_bn_act_bwd(const void* gin, const void* y, const float* scale
                               unsigned stream_id, unsigned rank, void* stream) {
     VAE_CHECK(gin && y && scale && shift && mean && rstd && partial && sums && dy, "vae_bn_act_bwd: null pointer");
     if (int e = check_geom("vae_bn_act_bwd", n_img, H, W, C, pool)) return e;
-    ActGeom g = {n_img, H, W, C, pool};
+    ActGeom g = {n_img, H, W, C, pool, pow2_shift(W >> 1), pow2_shift(H >> 1)};
     const DropCfg d = make_drop(p_drop, keep_mask, seed, step, stream_id, rank);
     const int nb = vae_bn_act_bwd_blocks(n_img, H, W, C, pool);
     const float inv_count = (float)(1.0 / ((double)n_img * H * W));
@@ -629,7 +653,8 @@ extern "C" int vae_head_fwd(const void* y, const float* scale, const float* shif
 extern "C" int vae_head_bwd_blocks(int n_img, int H, int W) {
     long b = ((long)n_img * H * W + 31) / 32;
     if (b < 1) b = 1;
-    if (b > 512) b = 512;
+    static const long cap = getenv("VAE_RED_GRID") ? atol(getenv("VAE_RED_GRID")) : 512;
+    if (b > cap) b = cap;
     return (int)b;
 }
 
