@@ -44,9 +44,19 @@ struct PatchTN {
 };
 
 constexpr int PT_BM = 128;
-constexpr int PT_ROWS_MAX = 288;                       // 8 images of 4x4: 8 * 6 * 6
-constexpr int PT_Q_INSTR = PT_ROWS_MAX / 8 / 4;        // global_load_lds instructions per wave: 9
 constexpr int PT_ROWB = 128;
+// patch rows reserved in LDS per image width (the largest patch any covered H gives, rounded up to 8):
+// W=4: 8 images of 4x4 = 8*6*6; W=8: 2 images of 8x8 = 2*10*10; W=16: 2 images of 4x16 = 2*6*18;
+// W=32: 4 rows = 6*34; W=64: 2 rows = 4*66
+constexpr int pt_rows(int W) { return W == 4 ? 288 : W == 8 ? 200 : W == 16 ? 216 : W == 32 ? 208 : 264; }
+
+// s_waitcnt vmcnt(groups * PER) for a wave-uniform runtime group count in [0, 2]
+template <int PER>
+__device__ __forceinline__ void pt_wait_groups(int groups) {
+    if (groups <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (groups == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+}
 
 __device__ __forceinline__ float pt_row16_sum(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
@@ -62,26 +72,29 @@ __global__ __launch_bounds__(256, 2) void conv3_patch_tn_kernel(const PatchTN p)
     constexpr int WAVES_M = BN == 128 ? 2 : 4, WAVES_N = 4 / WAVES_M;
     constexpr int TM = PT_BM / WAVES_M, TN = BN / WAVES_N;      // wave tile: TM pixels x TN channels
     constexpr int FM = TM / 16, FN = TN / 16;
-    constexpr int Q_BYTES = PT_ROWS_MAX * PT_ROWB, B_BYTES = BN * PT_ROWB;
+    constexpr int Q_BYTES = pt_rows(W) * PT_ROWB, B_BYTES = BN * PT_ROWB;
     constexpr int B_INSTR = BN / 8 / 4;
+    constexpr int Q_INSTR = (pt_rows(W) / 8 + 3) / 4;           // patch copies per wave
+    // weight tiles sit in a ring as deep as lets two workgroups share a CU (80 KB each), at most 4
+    constexpr int DEPTH = (81920 - Q_BYTES) / B_BYTES >= 4 ? 4 : (81920 - Q_BYTES) / B_BYTES;
     static_assert(TN == 64, "wave tile is 64 channels wide");
+    static_assert(DEPTH >= 2, "ring depth");
 
-    __shared__ __attribute__((aligned(16))) unsigned char smem[Q_BYTES + 2 * B_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[Q_BYTES + DEPTH * B_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int n0 = blockIdx.y * BN;
     int m0 = 0, h0 = 0;          // first pixel of the current tile and its image row (set per tile below)
-    const bf16_t* zero = (const bf16_t*)g_zero_page;
     const int K = 9 * p.C;
 
     // ---- patch staging: each lane's patch rows are fixed for the lifetime of the workgroup ----
     // packed: bits 0-9 pixel offset inside the tile + 256, 10-17 image-row offset r + 1, 18-20 source chunk,
     // bit 24 "row holds a pixel" (else padding: left/right halo or past the patch)
-    int q_st[PT_Q_INSTR];
+    int q_st[Q_INSTR];
     const int ninstr = (p.PR + 7) >> 3;
 #pragma unroll
-    for (int i = 0; i < PT_Q_INSTR; ++i) {
+    for (int i = 0; i < Q_INSTR; ++i) {
         const int prow = (wave + 4 * i) * 8 + (lane >> 3);
         // patch row -> (group, image row, column); exact float reciprocal division (operands < 2^9)
         const int per = (p.R + 2) * W2;
@@ -93,37 +106,42 @@ __global__ __launch_bounds__(256, 2) void conv3_patch_tn_kernel(const PatchTN p)
         q_st[i] = st;
     }
     const unsigned rowb = (unsigned)p.C * 2;
+    // copies are buffer_load ... lds: 32-bit byte offsets against descriptors in SGPRs; an offset past the
+    // buffer (OOB) delivers zeros -- the halo, rows past M and weight rows past N cost no pointer select
+    constexpr unsigned OOB = 0xFFFFFFFFu;
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)((unsigned)p.M * rowb), 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)((unsigned)p.N * (unsigned)K * 2u), 0x00020000);
 
     auto stage_patch = [&](int c0) {
-        const unsigned char* acol = (const unsigned char*)(p.A + c0);
 #pragma unroll
-        for (int i = 0; i < PT_Q_INSTR; ++i) {
+        for (int i = 0; i < Q_INSTR; ++i) {
             if (wave + 4 * i < ninstr) {     // wave-uniform
-                const unsigned char* src = (const unsigned char*)zero;
                 int st = q_st[i];
                 asm volatile("" : "+v"(st));      // unpack inside the loop: one register per instruction
                 const int m = m0 + (st & 1023) - 256, r = ((st >> 10) & 255) - 1;
+                unsigned off = OOB;
                 if ((st >> 24) && (unsigned)(h0 + r) < (unsigned)p.H && (unsigned)m < (unsigned)p.M)
-                    src = acol + ((unsigned)m * rowb + ((st >> 14) & 0x70));
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + (wave + 4 * i) * 1024), 16, 0, 0);
+                    off = (unsigned)m * rowb + (unsigned)(c0 * 2 + ((st >> 14) & 0x70));
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lptr_t)(smem + (wave + 4 * i) * 1024), 16, (int)off, 0, 0, 0);
             }
         }
     };
 
     // ---- weight tile staging -------------------------------------------------------------------
-    int b_off[B_INSTR];     // element offset of this lane's 16-byte chunk for tap 0, channel chunk 0 (-1: row >= N)
+    unsigned b_off[B_INSTR];     // byte offset of this lane's 16-byte chunk for tap 0, channel chunk 0 (OOB: row >= N)
 #pragma unroll
     for (int i = 0; i < B_INSTR; ++i) {
         const int row = (wave + 4 * i) * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-        b_off[i] = n0 + row < p.N ? (n0 + row) * K + chunk * 8 : -1;
+        b_off[i] = n0 + row < p.N ? ((unsigned)(n0 + row) * (unsigned)K + chunk * 8) * 2u : OOB;
     }
-    auto stage_b = [&](int buf, int koff) {      // koff = tap * C + c0
-        unsigned char* bbase = smem + Q_BYTES + buf * B_BYTES;
+    auto stage_b = [&](int slot, int koff) {      // koff = tap * C + c0
+        unsigned char* bbase = smem + Q_BYTES + slot * B_BYTES;
 #pragma unroll
         for (int i = 0; i < B_INSTR; ++i) {
-            const bf16_t* src = b_off[i] >= 0 ? p.B + b_off[i] + koff : zero;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(bbase + (wave + 4 * i) * 1024), 16, 0, 0);
+            const unsigned off = b_off[i] == OOB ? OOB : b_off[i] + (unsigned)(koff * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (lptr_t)(bbase + (wave + 4 * i) * 1024), 16, (int)off, 0, 0, 0);
         }
     };
 
@@ -153,9 +171,10 @@ __global__ __launch_bounds__(256, 2) void conv3_patch_tn_kernel(const PatchTN p)
     // ---- persistent loop over pixel tiles: the address tables above are computed once per workgroup ----
     const int nchunk = p.C / 64;
     const int ntiles = (p.M + PT_BM - 1) / PT_BM;
-    int par = 0;                                   // weight buffer holding the current tap
+    const int nsteps = 9 * nchunk;                 // K-steps per tile: one (channel chunk, tap) each
+    int slot = 0;                                  // ring slot of the current K-step's weight tile
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    if (tile != (int)blockIdx.x) __syncthreads();  // the statistics scratch of the previous tile has been read
+    if (tile != (int)blockIdx.x) __syncthreads();  // the previous tile's patch, weights and statistics scratch are done with
     m0 = tile * PT_BM;
     h0 = p.G == 1 ? ((m0 >> p.wshift) & (p.H - 1)) : 0;
     f32x4 acc[FM][FN];
@@ -165,17 +184,26 @@ __global__ __launch_bounds__(256, 2) void conv3_patch_tn_kernel(const PatchTN p)
         for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     stage_patch(0);
-    stage_b(par, 0);
+#pragma unroll
+    for (int q = 0; q < DEPTH - 1; ++q)            // K-steps 0 .. DEPTH-2 (nsteps >= 9 > DEPTH)
+        stage_b((slot + q) % DEPTH, q * p.C);
     for (int c = 0; c < nchunk; ++c) {
         const int c0 = c * 64;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // K-step s = 9c + tap needs its weight tile (and, on the first tap of a chunk, the patch, which was
+            // issued last): everything but the copies of the next min(DEPTH-2, steps left) K-steps must have landed
+            const int left = nsteps - 1 - (9 * c + tap);
+            if (tap == 0 && c > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else pt_wait_groups<B_INSTR>(left < DEPTH - 2 ? left : DEPTH - 2);
             __syncthreads();
-            if (tap + 1 < 9) stage_b(par ^ 1, (tap + 1) * p.C + c0);
-            else if (c + 1 < nchunk) stage_b(par ^ 1, c0 + 64);
+            {   // refill the slot read in the previous K-step with the tile of K-step s + DEPTH - 1
+                const int t2 = tap + DEPTH - 1;
+                const int tapn = t2 >= 9 ? t2 - 9 : t2, cn = t2 >= 9 ? c + 1 : c;
+                if (cn < nchunk) stage_b((slot + DEPTH - 1) % DEPTH, tapn * p.C + cn * 64);
+            }
             const int dh = tap / 3, dw = tap % 3;
-            const int boff = par * B_BYTES;
+            const int boff = slot * B_BYTES;
             bf16x8 xa[2][FM], wb[2][FN];
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
@@ -192,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void conv3_patch_tn_kernel(const PatchTN p)
 #pragma unroll
                     for (int j = 0; j < FN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[kk][j], xa[kk][i], acc[i][j], 0, 0, 0);
-            par ^= 1;
+            slot = slot + 1 == DEPTH ? 0 : slot + 1;
         }
         if (c + 1 < nchunk) {
             __syncthreads();            // every wave has read the last tap of this chunk's patch
@@ -277,6 +305,10 @@ bool conv3_patch_tn_ok(int n_img, int H, int W, int Cin, int Cout) {
     if (Cin % 64 || Cout % 64) return false;
     const long hw = (long)H * W;
     if (hw < 128 && (128 % hw || hw < 16)) return false;
+    {   // the patch must fit the rows reserved for this width
+        const int R = hw >= 128 ? 128 / W : H, G = hw >= 128 ? 1 : (int)(128 / hw);
+        if (G * (R + 2) * (W + 2) > pt_rows(W)) return false;
+    }
     if ((long)n_img * hw * (Cin > Cout ? Cin : Cout) * 2 >= (1L << 32)) return false;
     if ((long)Cout * 9 * Cin >= (1L << 30)) return false;
     return true;
@@ -294,7 +326,7 @@ int conv3_patch_tn_launch(const void* x, const void* w_packed, const float* bias
     p.rwshift = pt_ilog2(p.R * W);
     p.PR = p.G * (p.R + 2) * (W + 2);
     p.inv_per = 1.0f / (float)((p.R + 2) * (W + 2));
-    VAE_CHECK(p.PR <= PT_ROWS_MAX && p.rwshift >= 0, "conv3 patch kernel: internal geometry error (PR=%d)", p.PR);
+    VAE_CHECK(p.PR <= pt_rows(W) && p.rwshift >= 0, "conv3 patch kernel: internal geometry error (PR=%d)", p.PR);
     const int bn = Cout % 128 == 0 ? 128 : 64;
     const int ntiles = (p.M + PT_BM - 1) / PT_BM, gy = Cout / bn;
     int gx = 512 / gy;                       // two resident workgroups per CU, each walking ntiles / gx tiles

@@ -61,15 +61,21 @@ __device__ __forceinline__ bf16x8 tr_pair(const unsigned char* lo_addr, const un
     return __builtin_bit_cast(bf16x8, v);
 }
 
+// 512 threads = two groups of four waves.  Both groups hold the same 64 x 9 x 64 accumulator tile and walk the
+// workgroup's K range two K tiles at a time (group g takes tiles beg+g, beg+2+g, ...); at the end group 1 hands
+// its accumulators to group 0 through LDS, so one slab is written per workgroup: half the split-K bytes of
+// two independent 256-thread workgroups at the same number of resident waves.
 template <int W>
-__global__ __launch_bounds__(256, 2) void conv3_wgrad_patch_kernel(const PatchP p) {
+__global__ __launch_bounds__(512, 1) void conv3_wgrad_patch_kernel(const PatchP p) {
     constexpr int W2 = W + 2;
     constexpr int P_BYTES = 64 * ROWB, Q_BYTES = PATCH_ROWS_MAX * ROWB, STAGE = P_BYTES + Q_BYTES;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+    constexpr int FOLD_BYTES = 9 * 4 * 4 * 64 * 16;       // one group's accumulators: 36 float4 per lane, 4 waves
+    constexpr int SMEM_BYTES = 4 * STAGE > FOLD_BYTES ? 4 * STAGE : FOLD_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, grp = tid >> 8, wave = (tid >> 6) & 3;
     const int n0 = blockIdx.x * 64, m0 = blockIdx.y * 64, split = blockIdx.z;
-    const int kt_beg = split * p.kps, kt_end = min(kt_beg + p.kps, p.ktiles);
+    const int kt_beg = split * p.kps + grp, kt_end = min(split * p.kps + p.kps, p.ktiles);   // this group's tiles: stride 2
     const bf16_t* zero = (const bf16_t*)g_zero_page;
 
     // ---- per-lane patch staging state (the lane's patch rows never change) -------------
@@ -91,7 +97,7 @@ __global__ __launch_bounds__(256, 2) void conv3_wgrad_patch_kernel(const PatchP 
     const int p_ch0 = (lane & 7) ^ swz128(p_row0);
 
     auto stage = [&](int buf, int kt) {
-        unsigned char* pbase = smem + buf * STAGE;
+        unsigned char* pbase = smem + (2 * buf + grp) * STAGE;
         unsigned char* qbase = pbase + P_BYTES;
         const int k0 = kt * 64;
         {
@@ -158,11 +164,14 @@ __global__ __launch_bounds__(256, 2) void conv3_wgrad_patch_kernel(const PatchP 
     };
 
     if (kt_beg < kt_end) stage(0, kt_beg);
-    for (int kt = kt_beg; kt < kt_end; ++kt) {
+    const int niter = (min(split * p.kps + p.kps, p.ktiles) - split * p.kps + 1) >> 1;   // same for both groups
+    for (int it = 0; it < niter; ++it) {
+        const int kt = kt_beg + 2 * it;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (kt + 1 < kt_end) stage((kt + 1 - kt_beg) & 1, kt + 1);
-        const unsigned char* sbase = smem + ((kt - kt_beg) & 1) * STAGE;
+        if (kt + 2 < kt_end) stage((it + 1) & 1, kt + 2);
+        if (kt >= kt_end) continue;                       // odd tile count: group 1 idles in the last round
+        const unsigned char* sbase = smem + (2 * (it & 1) + grp) * STAGE;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8 pb[4];
@@ -186,6 +195,26 @@ __global__ __launch_bounds__(256, 2) void conv3_wgrad_patch_kernel(const PatchP 
             }
         }
     }
+
+    // fold group 1 into group 0 through LDS (the staging buffers are dead)
+    __syncthreads();
+    float4* fold = (float4*)smem + (wave * 64 + lane);
+    if (grp == 1) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                fold[(t * 4 + j) * 256] = make_float4(acc[t][j][0], acc[t][j][1], acc[t][j][2], acc[t][j][3]);
+    }
+    __syncthreads();
+    if (grp == 1) return;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 o = fold[(t * 4 + j) * 256];
+            acc[t][j][0] += o.x; acc[t][j][1] += o.y; acc[t][j][2] += o.z; acc[t][j][3] += o.w;
+        }
 
     // acc[t][j][r]: ci = n0 + wave*16 + (lane>>4)*4 + r ; co = m0 + j*16 + (lane&15)
     float* out = p.slab + (long)split * p.slab_stride;
@@ -223,10 +252,10 @@ extern "C" int vae_conv3_wgrad_patch_ok(int H, int W, int Cin, int Cout) {
 extern "C" int vae_conv3_wgrad_patch_ksplit(int n_img, int H, int W, int Cin, int Cout) {
     const long ktiles = ((long)n_img * H * W + 63) / 64;
     const long tiles = (long)(Cin / 64) * (Cout / 64);
-    long s = (512 + tiles - 1) / tiles;          // two workgroups per CU
-    const long maxs = ktiles / 4 > 0 ? ktiles / 4 : 1;
+    long s = (256 + tiles - 1) / tiles;          // one 512-thread workgroup per CU
+    const long maxs = ktiles / 8 > 0 ? ktiles / 8 : 1;
     if (s > maxs) s = maxs;
-    if (s > 512) s = 512;
+    if (s > 256) s = 256;
     if (s < 1) s = 1;
     const long kps = (ktiles + s - 1) / s;
     return (int)((ktiles + kps - 1) / kps);
@@ -259,11 +288,11 @@ extern "C" int vae_conv3_wgrad_patch(const void* dy, const void* x, float* slab,
     const double bytes = 2.0 * p.Ktot * ((double)Cout + Cin) + 4.0 * nsplit * 9.0 * Cout * Cin;
     ProfScope prof("conv3_wgrad_patch_kernel", flops, bytes, s);
     switch (W) {
-        case 4: hipLaunchKernelGGL(conv3_wgrad_patch_kernel<4>, grid, dim3(256), 0, s, p); break;
-        case 8: hipLaunchKernelGGL(conv3_wgrad_patch_kernel<8>, grid, dim3(256), 0, s, p); break;
-        case 16: hipLaunchKernelGGL(conv3_wgrad_patch_kernel<16>, grid, dim3(256), 0, s, p); break;
-        case 32: hipLaunchKernelGGL(conv3_wgrad_patch_kernel<32>, grid, dim3(256), 0, s, p); break;
-        default: hipLaunchKernelGGL(conv3_wgrad_patch_kernel<64>, grid, dim3(256), 0, s, p); break;
+        case 4: hipLaunchKernelGGL(conv3_wgrad_patch_kernel<4>, grid, dim3(512), 0, s, p); break;
+        case 8: hipLaunchKernelGGL(conv3_wgrad_patch_kernel<8>, grid, dim3(512), 0, s, p); break;
+        case 16: hipLaunchKernelGGL(conv3_wgrad_patch_kernel<16>, grid, dim3(512), 0, s, p); break;
+        case 32: hipLaunchKernelGGL(conv3_wgrad_patch_kernel<32>, grid, dim3(512), 0, s, p); break;
+        default: hipLaunchKernelGGL(conv3_wgrad_patch_kernel<64>, grid, dim3(512), 0, s, p); break;
     }
     VAE_LAUNCH_CHECK("conv3_wgrad_patch_kernel");
     return 0;

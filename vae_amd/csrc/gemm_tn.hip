@@ -12,9 +12,10 @@
 //   A_CONV3_C8     the network input padded to 8 channels (16 B per pixel): every 16-byte chunk
 //                  of a row is ONE tap's pixel; K = 16 taps x 8 channels, taps >= 9 are zero
 //                                                                      (first conv, Cin <= 8)
-// Tiles are staged global -> LDS with global_load_lds (16 B per lane, no VGPR round trip);
-// the LDS image is lane-linear, the XOR bank swizzle is applied to the per-lane SOURCE chunk
-// and again on the fragment read.  Double-buffered, one barrier per K-step.
+// Tiles are staged global -> LDS with buffer_load ... lds (16 B per lane, no VGPR round trip;
+// out-of-range offsets deliver the zeros of the padding); the LDS image is lane-linear, the XOR
+// bank swizzle is applied to the per-lane SOURCE chunk and again on the fragment read.  The
+// stages form a ring of 2-4 K-steps, one barrier per K-step.
 //
 // MFMA orientation: weights are the MFMA "A" operand (rows = output channels) and activations
 // the "B" operand (columns = pixels), so a lane ends up holding 4 CONSECUTIVE channels of one
@@ -419,7 +420,7 @@ extern "C" int vae_conv3x3_gemm(const void* x, const void* w_packed, const float
     p.bytes = 2.0 * ((double)p.M * Cin + (double)p.N * p.K + (double)p.M * Cout);
     if (int e = check_common(p, 64, "vae_conv3x3_gemm", (double)p.M * Cin)) return e;
     // big layers on power-of-two images: the patch-staged kernel (conv3_patch_tn.hip); same tile height, same statistics rows
-    if ((pick_bm(p.M, p.N) == 128 || getenv("VAE_FORCE_PATCH")) && conv3_patch_tn_ok(n_img, H, W, Cin, Cout))
+    if (pick_bm(p.M, p.N) == 128 && conv3_patch_tn_ok(n_img, H, W, Cin, Cout))
         return conv3_patch_tn_launch(x, w_packed, bias, y, stat_sum, stat_sq, n_img, H, W, Cin, Cout, p.flops, p.bytes,
                                      (hipStream_t)stream);
     return launch_bk64<A_CONV3, E_BF16>(p, (hipStream_t)stream);

@@ -536,8 +536,7 @@ static int check_geom(const char* who, int n_img, int H, int W, int C, int pool)
 static int elem_grid(long items) {
     long b = (items + 255) / 256;
     if (b < 1) b = 1;
-    static const long cap = getenv("VAE_ELEM_GRID") ? atol(getenv("VAE_ELEM_GRID")) : 2048;
-    if (b > cap) b = cap;
+    if (b > 2048) b = 2048;
     return (int)b;
 }
 
@@ -600,8 +599,7 @@ extern "C" int vae_bn_act_bwd_blocks(int n_img, int H, int W, int C, int pool) {
     const long items = (long)n_img * H * W / (pool ? 4 : 1) * (C / 8);
     long b = (items + 255) / 256;
     if (b < 1) b = 1;
-    static const long cap = getenv("VAE_RED_GRID") ? atol(getenv("VAE_RED_GRID")) : 512;
-    if (b > cap) b = cap;
+    if (b > 512) b = 512;
     return (int)b;
 }
 
@@ -653,8 +651,7 @@ extern "C" int vae_head_fwd(const void* y, const float* scale, const float* shif
 extern "C" int vae_head_bwd_blocks(int n_img, int H, int W) {
     long b = ((long)n_img * H * W + 31) / 32;
     if (b < 1) b = 1;
-    static const long cap = getenv("VAE_RED_GRID") ? atol(getenv("VAE_RED_GRID")) : 512;
-    if (b > cap) b = cap;
+    if (b > 512) b = 512;
     return (int)b;
 }
 
