@@ -106,8 +106,47 @@ def cpu_baseline(budget_s=15.0):
             "ms_per_step": 1e3 * dt / n}
 
 
+def bench_decode(args, model, conf, batch, Lat, S, world, rank, dev):
+    """sampling throughput: recon = model.decode(z), eval mode, z ~ N(0,1) resident in HBM; replicas only
+    (no collective): every rank decodes its own batches."""
+    import torch.distributed as dist
+    model.eval()
+    g = torch.Generator(device=dev).manual_seed(int(conf.seed) + rank)
+    zs = [torch.randn(batch, Lat, device=dev, generator=g) for _ in range(8)]
+    with torch.no_grad():
+        for i in range(args.warmup):
+            model.decode(zs[i % 8])
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            out = model.decode(zs[i % 8])
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    if rank == 0:
+        print(json.dumps({
+            "metric": "z->image decodes/sec (whole node)", "value": world * batch * args.steps / elapsed, "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{args.config}: VAEConv decode(z), latent {Lat}, {S}x{S}, eval mode, batch {batch} per GPU",
+                       "global_batch": world * batch, "parallelism": f"replicas x{world}"},
+            "checksum": float(out.float().mean())}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--mode", choices=["train", "decode"], default="train")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
@@ -150,6 +189,8 @@ def main():
         opt = torch.optim.AdamW(model.parameters(), lr=float(conf.lr))
     else:
         opt = FlatAdamW(model, lr=float(conf.lr))
+    if args.mode == "decode":
+        return bench_decode(args, model, conf, batch, Lat, S, world, rank, dev)
     reducer = None
     if world > 1:
         reducer = BucketedReducer(model.flat_grads, stage_ranges(model._offsets, model.flat_grads.numel()))

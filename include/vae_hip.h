@@ -90,9 +90,15 @@ unsigned vae_dropout_threshold(double p_drop);
  * 128 or, for small problems, 64 = vae_gemm_rows_per_block(), the bound to size buffers with). */
 int vae_gemm_rows_per_block(void);
 int vae_gemm_stat_rows(long M, int N);
+/* partial-statistics rows vae_conv3x3_gemm writes for a geometry (its patch-staged kernel keeps
+ * one row per workgroup, the generic kernel one per row tile); never more than
+ * vae_gemm_stat_rows(n*H*W, Cout).  Belongs to the BatchNorm that follows the conv,
+ * vae/models/vae.py:130,134. */
+int vae_conv3x3_stat_rows(int n_img, int H, int W, int Cin, int Cout);
 /* nn.Conv2d(Cin, Cout, 3, padding=1) forward, vae/models/vae.py:129,133 -- and, with the
  * flipped/transposed weight pack, its dgrad.  x [n,H,W,Cin], w_packed [Cout][9][Cin],
- * y [n,H,W,Cout].  stat_* (optional): per-workgroup per-channel sum / sum of squares of y. */
+ * y [n,H,W,Cout].  stat_* (optional): vae_conv3x3_stat_rows partial rows of per-channel
+ * sum / sum of squares of y. */
 int vae_conv3x3_gemm(const void* x, const void* w_packed, const float* bias, void* y,
                      float* stat_sum, float* stat_sq, int n_img, int H, int W, int Cin, int Cout,
                      void* stream);

@@ -174,7 +174,8 @@ def test_conv3x3_fwd_dgrad(L, n, H, W, Ci, Co):
     b = torch.randn(Co, generator=g)
     ref = F.conv2d(x, w, b, padding=1)
     M = n * H * W
-    gm = L.call("vae_gemm_stat_rows", M, Co)
+    gm = L.call("vae_conv3x3_stat_rows", n, H, W, Ci, Co)
+    assert 1 <= gm <= L.call("vae_gemm_stat_rows", M, Co)
     assert gm <= (M + L.call("vae_gemm_rows_per_block") - 1) // L.call("vae_gemm_rows_per_block")
     y = torch.full((n, H, W, Co), float("nan"), device=DEV, dtype=torch.bfloat16)
     ssum = torch.full((gm, Co), float("nan"), device=DEV)

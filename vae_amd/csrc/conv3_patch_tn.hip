@@ -76,11 +76,12 @@ __global__ __launch_bounds__(256, 2) void conv3_patch_tn_kernel(const PatchTN p)
     constexpr int B_INSTR = BN / 8 / 4;
     constexpr int Q_INSTR = (pt_rows(W) / 8 + 3) / 4;           // patch copies per wave
     // weight tiles sit in a ring as deep as lets two workgroups share a CU (80 KB each), at most 4
-    constexpr int DEPTH = (81920 - Q_BYTES) / B_BYTES >= 4 ? 4 : (81920 - Q_BYTES) / B_BYTES;
+    constexpr int DEPTH = (81920 - 2048 - Q_BYTES) / B_BYTES >= 4 ? 4 : (81920 - 2048 - Q_BYTES) / B_BYTES;
     static_assert(TN == 64, "wave tile is 64 channels wide");
     static_assert(DEPTH >= 2, "ring depth");
 
-    __shared__ __attribute__((aligned(16))) unsigned char smem[Q_BYTES + DEPTH * B_BYTES];
+    constexpr int RED_BYTES = 2 * WAVES_M * BN * 4;                // statistics accumulators
+    __shared__ __attribute__((aligned(16))) unsigned char smem[Q_BYTES + DEPTH * B_BYTES + RED_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -146,7 +147,9 @@ __global__ __launch_bounds__(256, 2) void conv3_patch_tn_kernel(const PatchTN p)
     };
 
     // ---- fragment addresses --------------------------------------------------------------------
-    int a_addr[FM][3][2];      // [pixel fragment][dw + 1][kk], tap row dh = -1; (dh + 1) * W2 * 128 is an immediate
+    // [pixel fragment][dw + 1] for the first 32 channels of the chunk (kk = 0), tap row dh = -1; (dh + 1) * W2 * 128 is
+    // an immediate; the second 32 channels flip bit 6 (chunk index bit 2), one XOR per read instead of a register
+    int a_addr[FM][3];
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         const int ml = wm * TM + i * 16 + (lane & 15);
@@ -155,17 +158,13 @@ __global__ __launch_bounds__(256, 2) void conv3_patch_tn_kernel(const PatchTN p)
         const int prow = (g * (p.R + 2) + r) * W2 + x + 1;            // the pixel one image row up
 #pragma unroll
         for (int d = 0; d < 3; ++d)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-                a_addr[i][d][kk] = (prow + d - 1) * PT_ROWB + (((kk * 4 + (lane >> 4)) ^ (((x + d) >> 1) & 7)) << 4);
+            a_addr[i][d] = (prow + d - 1) * PT_ROWB + (((lane >> 4) ^ (((x + d) >> 1) & 7)) << 4);
     }
-    int b_addr[FN][2];
+    int b_addr[FN];
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
         const int row = wn * TN + j * 16 + (lane & 15);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-            b_addr[j][kk] = Q_BYTES + row * PT_ROWB + (((kk * 4 + (lane >> 4)) ^ ((row >> 1) & 7)) << 4);
+        b_addr[j] = Q_BYTES + row * PT_ROWB + (((lane >> 4) ^ ((row >> 1) & 7)) << 4);
     }
 
     // ---- persistent loop over pixel tiles: the address tables above are computed once per workgroup ----
@@ -173,8 +172,14 @@ __global__ __launch_bounds__(256, 2) void conv3_patch_tn_kernel(const PatchTN p)
     const int ntiles = (p.M + PT_BM - 1) / PT_BM;
     const int nsteps = 9 * nchunk;                 // K-steps per tile: one (channel chunk, tap) each
     int slot = 0;                                  // ring slot of the current K-step's weight tile
+    // per-channel statistics of the stored values accumulate over all the tiles of this workgroup in a small LDS
+    // array [sum | sum of squares][wave row][channel] (each slot has one owning lane: no atomics, no barrier) and
+    // leave as ONE partial row per workgroup
+    const bool want_stats = p.stat_sum != nullptr;
+    float* red = (float*)(smem + Q_BYTES + DEPTH * B_BYTES);
+    for (int i = tid; i < 2 * WAVES_M * BN; i += 256) red[i] = 0.f;     // first read is many barriers away
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    if (tile != (int)blockIdx.x) __syncthreads();  // the previous tile's patch, weights and statistics scratch are done with
+    if (tile != (int)blockIdx.x) __syncthreads();  // the previous tile's patch and weight tiles are done with
     m0 = tile * PT_BM;
     h0 = p.G == 1 ? ((m0 >> p.wshift) & (p.H - 1)) : 0;
     f32x4 acc[FM][FN];
@@ -204,22 +209,27 @@ __global__ __launch_bounds__(256, 2) void conv3_patch_tn_kernel(const PatchTN p)
             }
             const int dh = tap / 3, dw = tap % 3;
             const int boff = slot * B_BYTES;
-            bf16x8 xa[2][FM], wb[2][FN];
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 xa[FM], wb[FN];
 #pragma unroll
-                for (int i = 0; i < FM; ++i)
-                    xa[kk][i] = *(const bf16x8*)(smem + a_addr[i][dw][kk] + dh * W2 * PT_ROWB);
+                for (int i = 0; i < FM; ++i) {
+                    int a = a_addr[i][dw];
+                    if (kk) asm volatile("v_xor_b32 %0, 64, %1" : "=v"(a) : "v"(a_addr[i][dw]));   // stays in the loop
+                    xa[i] = *(const bf16x8*)(smem + a + dh * W2 * PT_ROWB);
+                }
 #pragma unroll
-                for (int j = 0; j < FN; ++j) wb[kk][j] = *(const bf16x8*)(smem + b_addr[j][kk] + boff);
-            }
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
+                for (int j = 0; j < FN; ++j) {
+                    int b = b_addr[j];
+                    if (kk) asm volatile("v_xor_b32 %0, 64, %1" : "=v"(b) : "v"(b_addr[j]));
+                    wb[j] = *(const bf16x8*)(smem + b + boff);
+                }
 #pragma unroll
                 for (int i = 0; i < FM; ++i)
 #pragma unroll
                     for (int j = 0; j < FN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[kk][j], xa[kk][i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
+            }
             slot = slot + 1 == DEPTH ? 0 : slot + 1;
         }
         if (c + 1 < nchunk) {
@@ -228,20 +238,24 @@ __global__ __launch_bounds__(256, 2) void conv3_patch_tn_kernel(const PatchTN p)
         }
     }
 
-    // ---- epilogue: bias, bf16 store, per-channel sum / sum of squares of the stored values ----------
+    // ---- epilogue: bias, bf16 store ---------------------------------------------------------------
     // acc[i][j][r]: pixel m = m0 + wm*TM + i*16 + (lane&15), channel n = n0 + wn*TN + j*16 + (lane>>4)*4 + r
-    const bool want_stats = p.stat_sum != nullptr;
-    float ssum[FN][4], ssq[FN][4], bv[FN][4];
+    float bv[FN][4];     // (re)loaded per tile: 16 registers that need not live through the K loop
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
         const int n = n0 + wn * TN + j * 16 + (lane >> 4) * 4;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ssum[j][r] = ssq[j][r] = bv[j][r] = 0.f;
+        for (int r = 0; r < 4; ++r) bv[j][r] = 0.f;
         if (p.bias && n < p.N) {
             const float4 b4 = *(const float4*)(p.bias + n);
             bv[j][0] = b4.x; bv[j][1] = b4.y; bv[j][2] = b4.z; bv[j][3] = b4.w;
         }
     }
+    float ssum[FN][4], ssq[FN][4];
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ssum[j][r] = ssq[j][r] = 0.f;
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         const int m = m0 + wm * TM + i * 16 + (lane & 15);
@@ -260,29 +274,30 @@ __global__ __launch_bounds__(256, 2) void conv3_patch_tn_kernel(const PatchTN p)
         }
     }
     if (want_stats) {
-        __syncthreads();                 // the staging buffers are free
-        float* red = (float*)smem;       // [2][WAVES_M][BN]
 #pragma unroll
         for (int j = 0; j < FN; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float s = pt_row16_sum(ssum[j][r]), q = pt_row16_sum(ssq[j][r]);
-                if ((lane & 15) == 0) {
+                if ((lane & 15) == 0) {              // the one lane that owns this (wave row, channel) slot
                     const int cc = wn * TN + j * 16 + (lane >> 4) * 4 + r;
-                    red[wm * BN + cc] = s;
-                    red[(WAVES_M + wm) * BN + cc] = q;
+                    red[wm * BN + cc] += s;
+                    red[(WAVES_M + wm) * BN + cc] += q;
                 }
             }
+    }
+    }   // tile loop
+
+    if (want_stats) {
         __syncthreads();
         if (tid < BN && n0 + tid < p.N) {
             float s = 0.f, q = 0.f;
 #pragma unroll
             for (int w = 0; w < WAVES_M; ++w) { s += red[w * BN + tid]; q += red[(WAVES_M + w) * BN + tid]; }
-            p.stat_sum[(long)tile * p.N + n0 + tid] = s;
-            p.stat_sq[(long)tile * p.N + n0 + tid] = q;
+            p.stat_sum[(long)blockIdx.x * p.N + n0 + tid] = s;
+            p.stat_sq[(long)blockIdx.x * p.N + n0 + tid] = q;
         }
     }
-    }   // tile loop
 }
 
 static int pt_ilog2(int v) {
@@ -314,7 +329,16 @@ bool conv3_patch_tn_ok(int n_img, int H, int W, int Cin, int Cout) {
     return true;
 }
 
-// stat rows written: ceil(M / 128)
+// workgroups along M (each walks ceil(tiles / gx) pixel tiles) = statistics rows written
+int conv3_patch_tn_rows(long M, int Cout) {
+    const long ntiles = (M + PT_BM - 1) / PT_BM;
+    const int gy = Cout / (Cout % 128 == 0 ? 128 : 64);
+    long gx = 512 / gy;                      // two resident workgroups per CU
+    if (gx > ntiles) gx = ntiles;
+    if (gx < 1) gx = 1;
+    return (int)gx;
+}
+
 int conv3_patch_tn_launch(const void* x, const void* w_packed, const float* bias, void* y, float* stat_sum, float* stat_sq,
                           int n_img, int H, int W, int Cin, int Cout, double flops, double bytes, hipStream_t s) {
     PatchTN p = {};
@@ -328,11 +352,7 @@ int conv3_patch_tn_launch(const void* x, const void* w_packed, const float* bias
     p.inv_per = 1.0f / (float)((p.R + 2) * (W + 2));
     VAE_CHECK(p.PR <= pt_rows(W) && p.rwshift >= 0, "conv3 patch kernel: internal geometry error (PR=%d)", p.PR);
     const int bn = Cout % 128 == 0 ? 128 : 64;
-    const int ntiles = (p.M + PT_BM - 1) / PT_BM, gy = Cout / bn;
-    int gx = 512 / gy;                       // two resident workgroups per CU, each walking ntiles / gx tiles
-    if (gx > ntiles) gx = ntiles;
-    if (gx < 1) gx = 1;
-    dim3 grid(gx, gy);
+    dim3 grid(conv3_patch_tn_rows(p.M, Cout), Cout / bn);
     static char name[2][48] = {"conv3_patch_tn_kernel<64>", "conv3_patch_tn_kernel<128>"};
     ProfScope prof(name[bn == 128], flops, bytes, s);
     switch (W) {

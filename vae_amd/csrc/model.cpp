@@ -368,13 +368,14 @@ static int encoder_forward(const Ctx& c, const float* x, const void* const* mask
     for (int b = 0; b < 4; ++b) {
         const int H = d.S >> b, C = ENC_C[b];
         const long M = (long)d.N * H * H;
-        const int rows = vae_gemm_stat_rows(M, C);
+        const int rows_a = b == 0 ? vae_gemm_stat_rows(M, C) : vae_conv3x3_stat_rows(d.N, H, H, ENC_C[b - 1], C);
+        const int rows = vae_conv3x3_stat_rows(d.N, H, H, C, C);
         if (b == 0)
             TRY(vae_conv3x3_c8_gemm(in, c.pk_at(c.pk.c1a), c.P(1), c.at(w.ya[0]), ss, sq, d.N, H, H, C, c.stream));
         else
             TRY(vae_conv3x3_gemm(in, c.pk_at(c.pk.conv_f[2 * b - 1]), c.P(8 * b + 1), c.at(w.ya[b]), ss, sq, d.N, H, H,
                                  ENC_C[b - 1], C, c.stream));
-        TRY(bn_finalize(c, 2 * b, 8 * b + 2, rows, 1, (double)M));
+        TRY(bn_finalize(c, 2 * b, 8 * b + 2, rows_a, 1, (double)M));
         TRY(vae_bn_act_fwd(c.at(w.ya[b]), c.coef(2 * b, 0), c.coef(2 * b, 1), c.at(w.aa[b]), d.N, H, H, C, 0, 0.0, nullptr,
                            0, 0, 0, 0, c.stream));
         TRY(vae_conv3x3_gemm(c.at(w.aa[b]), c.pk_at(c.pk.conv_f[2 * b]), c.P(8 * b + 5), c.at(w.yb[b]), ss, sq, d.N, H, H, C,
