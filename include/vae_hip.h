@@ -122,6 +122,14 @@ int vae_convt2x2_dgrad_gemm(const void* dy, const void* w_packed, void* dx, int 
 int vae_linear_gemm(const void* a, const void* w, const float* bias, void* out, void* out2,
                     float* stat_sum, float* stat_sq, int M, int N, int K, int epilogue,
                     void* stream);
+/* The same nn.Linear forward / dgrad (vae/models/vae.py:96-97,116) for the fp32 epilogues when M
+ * is only the batch: the K range is cut into nsplit slabs [nsplit][M][N] (fp32, caller-provided)
+ * computed by separate workgroups and summed, with the bias, in a fixed order.
+ * vae_linear_splitk suggests nsplit (1 = not worth splitting). */
+int vae_linear_splitk(int M, int N, int K);
+int vae_linear_gemm_splitk(const void* a, const void* w, const float* bias, float* out, float* out2,
+                           float* slab, int nsplit, int M, int N, int K, int epilogue,
+                           void* stream);
 
 /* ---- weight gradients (what autograd computes for the layers above in loss.backward(),
  *      vae/training/train.py:332) ------------------------------------------------------------ */

@@ -37,6 +37,8 @@ SIGNATURES = {
     "vae_convt2x2_fwd_gemm": (None, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "vae_convt2x2_dgrad_gemm": (None, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "vae_linear_gemm": (None, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "vae_linear_splitk": (c_int, [c_int, c_int, c_int]),
+    "vae_linear_gemm_splitk": (None, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "vae_conv3x3_c8_gemm": (None, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "vae_wgrad_ksplit": (c_int, [c_int, c_int, c_int, c_long]),
     "vae_wgrad_gemm": (None, [P, P, P, c_int, c_int, c_long, c_int, c_int, c_int, c_int, c_int, c_int, P]),

@@ -52,6 +52,7 @@ struct GemmTN {
     int Co;               // E_CONVT: channels per tap
     int wshift, hshift;   // log2(W), log2(H) when both are powers of two, else -1
     unsigned a_bytes, b_bytes;   // sizes of A and B in bytes (buffer descriptors; both < 4 GiB)
+    int ksteps, nsplit;          // split-K: K-steps per workgroup along z and number of slabs (0, 0 = off)
     double flops, bytes;  // algorithmic work of this launch (profiling only)
 };
 
@@ -210,10 +211,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nk = p.K / BK;
+    // split-K (E_F32 only): workgroup z covers K-steps [z * ksteps, ...) and writes slab z of the output
+    const int ks0 = p.ksteps > 0 ? (int)blockIdx.z * p.ksteps : 0;
+    const int nk = p.ksteps > 0 ? min(p.ksteps, p.K / BK - ks0) : p.K / BK;
 #pragma unroll
     for (int q = 0; q < NST - 1; ++q)
-        if (q < nk) stage(q, q);
+        if (q < nk) stage(q, ks0 + q);
     int slot = 0;                     // ring slot of K-step ks
     for (int ks = 0; ks < nk; ++ks) {
         wait_vm_groups<A_INSTR + B_INSTR>(min(NST - 2, nk - 1 - ks));   // everything up to K-step ks has landed
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
                 wb[kk][j] = *(const bf16x8*)(bbase + row * ROWB + ((chunk ^ ((row >> SW) & (CH - 1))) << 4));
             }
         }
-        if (ks + NST - 1 < nk) stage(slot == 0 ? NST - 1 : slot - 1, ks + NST - 1);   // the slot read in K-step ks - 1
+        if (ks + NST - 1 < nk) stage(slot == 0 ? NST - 1 : slot - 1, ks0 + ks + NST - 1);   // the slot read in K-step ks - 1
         slot = slot + 1 == NST ? 0 : slot + 1;
 #pragma unroll
         for (int kk = 0; kk < BK / 32; ++kk)
@@ -304,7 +307,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
                                          : (float*)p.out2 + (long)m * p.split + (n - p.split);
                 *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
             } else {
-                *(float4*)((float*)p.out + (long)m * p.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
+                float* o = (float*)p.out + (p.ksteps > 0 ? (long)blockIdx.z * p.M * p.ldo : 0L);
+                *(float4*)(o + (long)m * p.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
             }
         }
     }
@@ -339,7 +343,7 @@ static int launch_one(const GemmTN& p, hipStream_t s) {
     // ring depth: as deep as lets two workgroups share a CU's 160 KB of LDS
     constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
     constexpr int NST = STAGE_BYTES <= 16384 ? 4 : STAGE_BYTES <= 24576 ? 3 : 2;
-    dim3 grid((p.M + BM - 1) / BM, (p.N + BN - 1) / BN);
+    dim3 grid((p.M + BM - 1) / BM, (p.N + BN - 1) / BN, p.ksteps > 0 ? p.nsplit : 1);
     static char name[64] = "";
     if (!name[0]) snprintf(name, sizeof(name), "gemm_tn_kernel<%d,%d,%d,%d,%d,%d>", BM, BN, BK, WAVES_M, AMODE, EPI);
     ProfScope prof(name, p.flops, p.bytes, s);
@@ -504,5 +508,74 @@ extern "C" int vae_linear_gemm(const void* a, const void* w, const float* bias, 
         default:
             VAE_CHECK(false, "vae_linear_gemm: unknown epilogue %d", epilogue);
     }
+    return 0;
+}
+
+// ---- split-K for small-M linear layers --------------------------------------------------------
+// With M = batch rows only, a [M][N] output has too few tiles to fill 256 CUs while K is thousands deep
+// (fc_mu | fc_logvar forward: 512 x 256 x 4096).  The K range is cut into nsplit slabs computed by
+// separate workgroups as fp32 [nsplit][M][N]; the finish kernel adds the slabs and the bias in a fixed
+// order (deterministic) and writes the output(s).
+namespace vae {
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ slab, int nsplit, long mn, int N,
+                                                            const float* __restrict__ bias, float* __restrict__ out,
+                                                            float* __restrict__ out2, int split) {
+    const long e = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (e >= mn) return;
+    const int n = (int)(e % N);
+    const long m = e / N;
+    float4 a = bias ? *(const float4*)(bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < nsplit; ++s) {
+        const float4 v = *(const float4*)(slab + (long)s * mn + e);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    if (split > 0) {
+        float* dst = n < split ? out + m * split + n : out2 + m * split + (n - split);
+        *(float4*)dst = a;
+    } else {
+        *(float4*)(out + e) = a;
+    }
+}
+}  // namespace vae
+
+extern "C" int vae_linear_splitk(int M, int N, int K) {
+    if (K % 64 != 0) return 1;
+    const long tiles = ((long)(M + 63) / 64) * ((N + 63) / 64);
+    const int nk = K / 64;
+    long s = (256 + tiles - 1) / tiles;
+    if (s > nk / 4) s = nk / 4;
+    if (s < 1) s = 1;
+    const long per = (nk + s - 1) / s;
+    return (int)((nk + per - 1) / per);
+}
+
+extern "C" int vae_linear_gemm_splitk(const void* a, const void* w, const float* bias, float* out, float* out2,
+                                      float* slab, int nsplit, int M, int N, int K, int epilogue, void* stream) {
+    VAE_CHECK(epilogue == VAE_EPI_F32 || epilogue == VAE_EPI_F32_SPLIT, "vae_linear_gemm_splitk: fp32 epilogues only");
+    VAE_CHECK(slab && out && K % 64 == 0, "vae_linear_gemm_splitk: needs a slab, an output and K a multiple of 64");
+    VAE_CHECK(nsplit >= 1 && nsplit <= K / 64, "vae_linear_gemm_splitk: nsplit=%d out of range", nsplit);
+    VAE_CHECK(N % 4 == 0 && ((uintptr_t)slab & 15) == 0 && ((uintptr_t)out & 15) == 0, "vae_linear_gemm_splitk: alignment");
+    int split = 0;
+    if (epilogue == VAE_EPI_F32_SPLIT) {
+        VAE_CHECK(out2 && N % 2 == 0 && (N / 2) % 4 == 0, "vae_linear_gemm_splitk: split epilogue needs out2 and N/2 a multiple of 4");
+        split = N / 2;
+    }
+    GemmTN p = {};
+    p.A = (const bf16_t*)a; p.B = (const bf16_t*)w; p.out = slab;
+    p.M = M; p.N = N; p.K = K; p.lda = K; p.ldo = N;
+    const int nk = K / 64;
+    p.ksteps = (nk + nsplit - 1) / nsplit;
+    p.nsplit = nsplit;
+    VAE_CHECK((long)(nsplit - 1) * p.ksteps < nk, "vae_linear_gemm_splitk: nsplit=%d leaves empty splits", nsplit);
+    p.flops = 2.0 * M * N * K;
+    p.bytes = 2.0 * ((double)M * K + (double)N * K) + 4.0 * M * N * (nsplit + 1.0);
+    hipStream_t s = (hipStream_t)stream;
+    if (int e = check_common(p, 64, "vae_linear_gemm_splitk", (double)M * K)) return e;
+    p.wshift = p.hshift = -1;
+    if (int e = launch_one<64, 64, 64, 2, A_PLAIN, E_F32>(p, s)) return e;
+    const long mn = (long)M * N;
+    hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)((mn / 4 + 255) / 256)), dim3(256), 0, s, slab, nsplit, mn, N, bias,
+                       out, out2, split);
+    VAE_LAUNCH_CHECK("splitk_finish_kernel");
     return 0;
 }

@@ -266,6 +266,15 @@ int bn_finalize(const Ctx& c, int bi, int g_idx, int rows, int fold, double coun
                            c.coef(bi, 1), c.coef(bi, 2), c.coef(bi, 3), c.stream);
 }
 
+// nn.Linear with an fp32 output and M = batch rows: split-K through the (idle) wgrad slab when that fills the chip
+int linear_f32(const Ctx& c, const void* a, const void* wgt, const float* bias, float* out, float* out2, int M, int N, int K,
+               int epilogue) {
+    const int ns = vae_linear_splitk(M, N, K);
+    if (ns > 1 && (long)ns * M * N <= c.ws.slab_floats)
+        return vae_linear_gemm_splitk(a, wgt, bias, out, out2, (float*)c.at(c.ws.slab), ns, M, N, K, epilogue, c.stream);
+    return vae_linear_gemm(a, wgt, bias, out, out2, nullptr, nullptr, M, N, K, epilogue, c.stream);
+}
+
 }  // namespace
 
 // ==================================================================== public API
@@ -386,8 +395,8 @@ static int encoder_forward(const Ctx& c, const float* x, const void* const* mask
                            c.stream));
         in = c.at(w.ob[b]);
     }
-    return vae_linear_gemm(in, c.pk_at(c.pk.fc_f), (const float*)c.pk_at(c.pk.bcat), mu, logvar, nullptr, nullptr, d.N,
-                           2 * d.L, d.F, VAE_EPI_F32_SPLIT, c.stream);
+    return linear_f32(c, in, c.pk_at(c.pk.fc_f), (const float*)c.pk_at(c.pk.bcat), mu, logvar, d.N, 2 * d.L, d.F,
+                      VAE_EPI_F32_SPLIT);
 }
 
 extern "C" int vae_model_forward(const vae_model_cfg* cfg, const float* params, float* bn_stats, const void* wpack,
@@ -490,8 +499,7 @@ static int backward_decoder(const Ctx& c, const float* d_recon, const float* rec
     // slab [(p, c)][l] -> fc_up.weight [(c, p)][l]
     TRY(reduce4((float*)c.at(w.slab), ns, (long)d.F * d.L, 0, c.G(P_FC_UP_W), d.hw, 256, d.L, 1, d.L, (long)d.hw * d.L, 1, 0,
                 c.stream));
-    TRY(vae_linear_gemm(c.at(w.dpre), c.pk_at(c.pk.up_d), nullptr, c.at(w.dz), nullptr, nullptr, nullptr, d.N, d.L, d.F,
-                        VAE_EPI_F32, c.stream));
+    TRY(linear_f32(c, c.at(w.dpre), c.pk_at(c.pk.up_d), nullptr, (float*)c.at(w.dz), nullptr, d.N, d.L, d.F, VAE_EPI_F32));
     TRY(vae_reparam_kl_bwd((const float*)c.at(w.dz), mu, logvar, eps_in, dmu_ext, dlv_ext, kl_scale, (float*)c.at(w.dmu),
                            (float*)c.at(w.dlv), c.at(w.dcat), (long)d.N * d.L, d.L, c.cfg->seed, c.cfg->step, c.cfg->rank,
                            c.stream));

@@ -76,19 +76,19 @@ __device__ __forceinline__ void act8(const float y[8], const float sc[8], const 
 
 // ---------------------------------------------------------------------------------------
 // batch statistics -> scale / shift / mean / rstd (+ running stats), one pass over the
-// per-workgroup partials left by the GEMM epilogue.  grid = ceil(C/64), block = 1024.
+// per-workgroup partials left by the GEMM epilogue.  grid = ceil(C/32), block = 1024.
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(
     const float* __restrict__ psum, const float* __restrict__ psq, int rows, int C, int fold, double count,
     const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ running_mean,
     float* __restrict__ running_var, float momentum, float eps, int use_running, float* __restrict__ scale,
     float* __restrict__ shift, float* __restrict__ mean_out, float* __restrict__ rstd_out) {
-    __shared__ double red[2][16][64];
-    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    __shared__ double red[2][32][33];
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;     // 32 channels x 32 row groups
+    const int c = blockIdx.x * 32 + cl;
     double s = 0.0, q = 0.0;
     if (!use_running && c < C) {
         const int ncols = fold * C;
-        for (int r = rg; r < rows; r += 16)
+        for (int r = rg; r < rows; r += 32)
             for (int t = 0; t < fold; ++t) {
                 s += (double)psum[(long)r * ncols + t * C + c];
                 q += (double)psq[(long)r * ncols + t * C + c];
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(
             var = running_var[c];
         } else {
 #pragma unroll
-            for (int i = 1; i < 16; ++i) { s += red[0][i][cl]; q += red[1][i][cl]; }
+            for (int i = 1; i < 32; ++i) { s += red[0][i][cl]; q += red[1][i][cl]; }
             const double m = s / count;
             double v = q / count - m * m;
             if (v < 0.0) v = 0.0;
@@ -148,20 +148,28 @@ __global__ __launch_bounds__(256) void stats_stage1_kernel(float* __restrict__ p
     }
 }
 
-// out[j] = sum_r partial[r][j]; grid = ceil(ncols/64), block = 1024
+// out[j] = sum_r partial[r][j]; grid = ceil(ncols/32), block = 1024 = 32 columns x 32 row groups (a launch of
+// this kernel is latency-bound: narrow column slices put more CUs on the few hundred KB of partials)
 __global__ __launch_bounds__(1024) void sum_partials_kernel(const float* __restrict__ partial, int rows, int ncols,
                                                             int ld, float* __restrict__ out, float mul) {
-    __shared__ double red[16][64];
-    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
-    double s = 0.0;
-    if (c < ncols)
-        for (int r = rg; r < rows; r += 16) s += (double)partial[(long)r * ld + c];
-    red[rg][cl] = s;
+    __shared__ double red[32][33];
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double s0 = 0.0, s1 = 0.0;
+    if (c < ncols) {
+        int r = rg;
+        for (; r + 32 < rows; r += 64) {           // two loads in flight per lane
+            s0 += (double)partial[(long)r * ld + c];
+            s1 += (double)partial[(long)(r + 32) * ld + c];
+        }
+        if (r < rows) s0 += (double)partial[(long)r * ld + c];
+    }
+    red[rg][cl] = s0 + s1;
     __syncthreads();
     if (rg == 0 && c < ncols) {
+        double s = 0.0;
 #pragma unroll
-        for (int i = 1; i < 16; ++i) s += red[i][cl];
+        for (int i = 0; i < 32; ++i) s += red[i][cl];
         out[c] = (float)(s * (double)mul);
     }
 }
@@ -562,7 +570,7 @@ extern "C" int vae_bn_finalize(float* stat_sum, float* stat_sq, int rows, int C,
         stat_sq += (long)rows * ncols;
         rows = VAE_STAT_SCRATCH_ROWS;
     }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, stat_sum, stat_sq,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, stat_sum, stat_sq,
                        rows, C, fold, count, gamma, beta, running_mean, running_var, momentum, eps, use_running, scale,
                        shift, mean, rstd);
     VAE_LAUNCH_CHECK("bn_finalize_kernel");
@@ -571,7 +579,7 @@ extern "C" int vae_bn_finalize(float* stat_sum, float* stat_sq, int rows, int C,
 
 extern "C" int vae_sum_partials(const float* partial, int rows, int ncols, float* out, float mul, void* stream) {
     VAE_CHECK(partial && out && rows > 0 && ncols > 0, "vae_sum_partials: bad arguments");
-    hipLaunchKernelGGL(sum_partials_kernel, dim3((ncols + 63) / 64), dim3(1024), 0, (hipStream_t)stream, partial, rows,
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((ncols + 31) / 32), dim3(1024), 0, (hipStream_t)stream, partial, rows,
                        ncols, ncols, out, mul);
     VAE_LAUNCH_CHECK("sum_partials_kernel");
     return 0;
@@ -623,7 +631,7 @@ extern "C" int vae_bn_act_bwd(const void* gin, const void* y, const float* scale
     if (pool) hipLaunchKernelGGL((bn_act_bwd_kernel<true, 0>), dim3(nb), dim3(256), 0, s, gi, yy, scale, shift, mean, rstd, sums, inv_count, partial, (bf16_t*)dy, g, d);
     else hipLaunchKernelGGL((bn_act_bwd_kernel<false, 0>), dim3(nb), dim3(256), 0, s, gi, yy, scale, shift, mean, rstd, sums, inv_count, partial, (bf16_t*)dy, g, d);
     VAE_LAUNCH_CHECK("bn_act_bwd_kernel<0>");
-    hipLaunchKernelGGL(sum_partials_kernel, dim3((2 * C + 63) / 64), dim3(1024), 0, s, partial, nb, 2 * C, 2 * C, sums, 1.0f);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((2 * C + 31) / 32), dim3(1024), 0, s, partial, nb, 2 * C, 2 * C, sums, 1.0f);
     VAE_LAUNCH_CHECK("sum_partials_kernel");
     const int nb2 = elem_grid((long)n_img * H * W / (pool ? 4 : 1) * (C / 8));
     if (pool) hipLaunchKernelGGL((bn_act_bwd_kernel<true, 1>), dim3(nb2), dim3(256), 0, s, gi, yy, scale, shift, mean, rstd, sums, inv_count, partial, (bf16_t*)dy, g, d);
@@ -672,9 +680,9 @@ extern "C" int vae_head_bwd(const float* drecon, const float* recon, const void*
     switch (Cout) { case 1: GO(1, 0, nb); break; case 2: GO(2, 0, nb); break; case 3: GO(3, 0, nb); break; default: GO(4, 0, nb); }
     VAE_LAUNCH_CHECK("head_bwd_kernel<0>");
     // [d gamma | d beta] -> sums (also the coefficients of pass 1); [dW | db] -> sums_head
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(2), dim3(1024), 0, s, partial, nb, 128, ncols, sums, 1.0f);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(4), dim3(1024), 0, s, partial, nb, 128, ncols, sums, 1.0f);
     const int nh = Cout * 64 + Cout;
-    hipLaunchKernelGGL(sum_partials_kernel, dim3((nh + 63) / 64), dim3(1024), 0, s, partial + 128, nb, nh, ncols, sums_head, 1.0f);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((nh + 31) / 32), dim3(1024), 0, s, partial + 128, nb, nh, ncols, sums_head, 1.0f);
     VAE_LAUNCH_CHECK("sum_partials_kernel");
     const int nb2 = (int)((npix + 31) / 32 > 2048 ? 2048 : (npix + 31) / 32);
     switch (Cout) { case 1: GO(1, 1, nb2); break; case 2: GO(2, 1, nb2); break; case 3: GO(3, 1, nb2); break; default: GO(4, 1, nb2); }
