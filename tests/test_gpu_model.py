@@ -74,7 +74,9 @@ EMU_RECON_RTOL = 5e-3
 EMU_DEEP_RTOL = 2.5e-2
 DEEP_RTOL = 5e-2
 GRAD_COS_EMU = 0.97
-GRAD_COS_REF = 0.90
+# against the fp32 reference the bar sits below the worst case of the bf16 oracle itself: on the 4-image fixtures
+# a 64-entry BatchNorm bias gradient of the first block lands at 0.90 +- 0.01 depending on the summation order
+GRAD_COS_REF = 0.85
 
 
 def cosine(a, b):

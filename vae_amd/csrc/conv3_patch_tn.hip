@@ -281,8 +281,9 @@ __global__ __launch_bounds__(256, 2) void conv3_patch_tn_kernel(const PatchTN p)
                 const float s = pt_row16_sum(ssum[j][r]), q = pt_row16_sum(ssq[j][r]);
                 if ((lane & 15) == 0) {              // the one lane that owns this (wave row, channel) slot
                     const int cc = wn * TN + j * 16 + (lane >> 4) * 4 + r;
-                    red[wm * BN + cc] += s;
-                    red[(WAVES_M + wm) * BN + cc] += q;
+                    // ds_add_f32 without return: fire and forget (a read-modify-write would wait ~100 cycles per slot)
+                    (void)__hip_atomic_fetch_add(&red[wm * BN + cc], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    (void)__hip_atomic_fetch_add(&red[(WAVES_M + wm) * BN + cc], q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
     }
@@ -330,9 +331,15 @@ bool conv3_patch_tn_ok(int n_img, int H, int W, int Cin, int Cout) {
 }
 
 // workgroups along M (each walks ceil(tiles / gx) pixel tiles) = statistics rows written
+// channel-tile width: 128 where that still gives every CU a workgroup, else 64 (twice the workgroups)
+static int pt_pick_bn(long M, int Cout) {
+    const long ntiles = (M + PT_BM - 1) / PT_BM;
+    return Cout % 128 == 0 && ntiles * (Cout / 128) >= 256 ? 128 : 64;
+}
+
 int conv3_patch_tn_rows(long M, int Cout) {
     const long ntiles = (M + PT_BM - 1) / PT_BM;
-    const int gy = Cout / (Cout % 128 == 0 ? 128 : 64);
+    const int gy = Cout / pt_pick_bn(M, Cout);
     long gx = 512 / gy;                      // two resident workgroups per CU
     if (gx > ntiles) gx = ntiles;
     if (gx < 1) gx = 1;
@@ -351,7 +358,7 @@ int conv3_patch_tn_launch(const void* x, const void* w_packed, const float* bias
     p.PR = p.G * (p.R + 2) * (W + 2);
     p.inv_per = 1.0f / (float)((p.R + 2) * (W + 2));
     VAE_CHECK(p.PR <= pt_rows(W) && p.rwshift >= 0, "conv3 patch kernel: internal geometry error (PR=%d)", p.PR);
-    const int bn = Cout % 128 == 0 ? 128 : 64;
+    const int bn = pt_pick_bn(p.M, Cout);
     dim3 grid(conv3_patch_tn_rows(p.M, Cout), Cout / bn);
     static char name[2][48] = {"conv3_patch_tn_kernel<64>", "conv3_patch_tn_kernel<128>"};
     ProfScope prof(name[bn == 128], flops, bytes, s);

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
     static_assert(FM >= 1 && FN >= 1 && A_INSTR >= 1 && B_INSTR >= 1, "tile too small");
     static_assert(NST >= 2 && NST <= 5, "ring depth");
     static_assert(NST * STAGE >= (int)(2 * WAVES_M * BN * sizeof(float)), "stats scratch does not fit");
-    static_assert((NST - 2) * 3 * (A_INSTR + B_INSTR) <= 63 || NST <= 4, "vmcnt range");
+    static_assert((NST - 2) * (A_INSTR + B_INSTR) <= 63, "vmcnt is a 6-bit counter");
 
     __shared__ __attribute__((aligned(16))) unsigned char smem[NST * STAGE];
 
@@ -343,11 +343,17 @@ static int launch_one(const GemmTN& p, hipStream_t s) {
     // ring depth: as deep as lets two workgroups share a CU's 160 KB of LDS
     constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
     constexpr int NST = STAGE_BYTES <= 16384 ? 4 : STAGE_BYTES <= 24576 ? 3 : 2;
+    // a grid of at most one workgroup per CU has the whole LDS to itself: 5 stages keep 4 K-steps of copies in
+    // flight, which is what it takes to cover an HBM round trip with the short K-steps of a small tile
+    constexpr int NST_DEEP = STAGE_BYTES * 5 <= 160 * 1024 ? 5 : NST;
     dim3 grid((p.M + BM - 1) / BM, (p.N + BN - 1) / BN, p.ksteps > 0 ? p.nsplit : 1);
     static char name[64] = "";
     if (!name[0]) snprintf(name, sizeof(name), "gemm_tn_kernel<%d,%d,%d,%d,%d,%d>", BM, BN, BK, WAVES_M, AMODE, EPI);
     ProfScope prof(name, p.flops, p.bytes, s);
-    hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, BK, WAVES_M, AMODE, EPI, NST>), grid, dim3(256), 0, s, p);
+    if (NST_DEEP != NST && (long)grid.x * grid.y * grid.z <= 256 && p.K / BK >= 8)
+        hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, BK, WAVES_M, AMODE, EPI, NST_DEEP>), grid, dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, BK, WAVES_M, AMODE, EPI, NST>), grid, dim3(256), 0, s, p);
     VAE_LAUNCH_CHECK("gemm_tn_kernel");
     return 0;
 }
@@ -413,7 +419,7 @@ extern "C" int vae_gemm_stat_rows(long M, int N) {
 
 extern "C" int vae_conv3x3_stat_rows(int n_img, int H, int W, int Cin, int Cout) {
     const long M = (long)n_img * H * W;
-    if (pick_bm(M, Cout) == 128 && conv3_patch_tn_ok(n_img, H, W, Cin, Cout)) return conv3_patch_tn_rows(M, Cout);
+    if (conv3_patch_tn_ok(n_img, H, W, Cin, Cout)) return conv3_patch_tn_rows(M, Cout);
     return vae_gemm_stat_rows(M, Cout);
 }
 
@@ -430,8 +436,8 @@ extern "C" int vae_conv3x3_gemm(const void* x, const void* w_packed, const float
     p.flops = 2.0 * p.M * p.N * p.K;
     p.bytes = 2.0 * ((double)p.M * Cin + (double)p.N * p.K + (double)p.M * Cout);
     if (int e = check_common(p, 64, "vae_conv3x3_gemm", (double)p.M * Cin)) return e;
-    // big layers on power-of-two images: the patch-staged kernel (conv3_patch_tn.hip); same tile height, same statistics rows
-    if (pick_bm(p.M, p.N) == 128 && conv3_patch_tn_ok(n_img, H, W, Cin, Cout))
+    // power-of-two images: the patch-staged kernel (conv3_patch_tn.hip)
+    if (conv3_patch_tn_ok(n_img, H, W, Cin, Cout))
         return conv3_patch_tn_launch(x, w_packed, bias, y, stat_sum, stat_sq, n_img, H, W, Cin, Cout, p.flops, p.bytes,
                                      (hipStream_t)stream);
     return launch_bk64<A_CONV3, E_BF16>(p, (hipStream_t)stream);
