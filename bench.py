@@ -78,6 +78,21 @@ def profile_pass(step_fn, batches, nsteps=3):
     return out
 
 
+def pmc_traffic(kernel, config):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE are
+    collected in separate profiler runs of this script and folded by tools_pmc_traffic.py; they cannot be
+    read from inside the timed process).  None when no measurement of this workload's kernel is on file."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if config != "cfg2_1gpu" or not os.path.exists(path):
+        return None
+    try:
+        with open(path) as f:
+            rec = json.load(f)["kernels"].get(kernel)
+        return rec["hbm_bytes_per_launch"] if rec else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def cpu_baseline(budget_s=15.0):
     """the CPU oracle's full train step at BASELINE config 1 (batch 64, fp32), timed on this host."""
     from oracle import vae_oracle as O
@@ -239,7 +254,8 @@ def main():
         if kernels:
             top = kernels[0]
             out["roofline"] = {"kernel": top["kernel"], "bound": top["bound"], "achieved": top["achieved"],
-                               "peak": top["peak"], "unit": top["unit"], "frac": top["frac"], "traffic": None,
+                               "peak": top["peak"], "unit": top["unit"], "frac": top["frac"],
+                               "traffic": pmc_traffic(top["kernel"], "" if args.batch else args.config),
                                "avg_us": top["avg_us"], "launches_per_step": top["launches_per_step"]}
             out["kernels"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in kernels[:24]]
             out["kernel_ms_per_step_sum"] = sum(r["ms_per_step"] for r in kernels)
