@@ -249,6 +249,9 @@ typedef struct vae_model_cfg {
     double p_dropout;
     unsigned long long seed; /* Philox key (config seed) */
     unsigned step, rank;     /* Philox counter words: forward-call index and data-parallel rank */
+    void* side_stream;       /* optional second hipStream_t: vae_model_backward runs the weight-gradient
+                              * kernels there, beside the dgrad / BatchNorm chain on `stream`, and
+                              * re-joins `stream` before it returns.  NULL: everything on `stream`. */
 } vae_model_cfg;
 
 long vae_model_param_count(const vae_model_cfg* cfg);              /* floats in params / grads */

@@ -86,7 +86,7 @@ class ModelCfg(ctypes.Structure):
     """mirror of struct vae_model_cfg (include/vae_hip.h)."""
     _fields_ = [("batch", c_int), ("in_channels", c_int), ("out_channels", c_int), ("latent", c_int),
                 ("image_size", c_int), ("train", c_int), ("p_dropout", c_double),
-                ("seed", c_ulonglong), ("step", c_uint), ("rank", c_uint)]
+                ("seed", c_ulonglong), ("step", c_uint), ("rank", c_uint), ("side_stream", c_void_p)]
 
 
 def long4(*v):

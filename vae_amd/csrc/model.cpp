@@ -141,8 +141,10 @@ struct WsLayout {
     long coef;              // 11 x 4 x 256 floats: scale, shift, mean, rstd
     long stat_sum, stat_sq; // GEMM epilogue partials
     long zb, klp, h, yd[3], ad[2];
-    long g0, g1, bnpart, headpart, headsums, slab, dz, dmu, dlv, dcat, dpre, colp;
+    long bnpart, headpart, headsums, slab, dz, dmu, dlv, dcat, dpre, colp;
     long slab_floats;
+    long g[3];              // gradient ping-pong buffers (three: a weight-gradient kernel may still read one)
+    long slab2, slab2_floats;
     long total_bytes;
 };
 
@@ -176,7 +178,7 @@ void make_ws_layout(const Dims& d, WsLayout* w) {
         w->yd[u] = put((long)d.N * hh * hh * DEC_CO[u] * 2);
         if (u < 2) w->ad[u] = put((long)d.N * hh * hh * DEC_CO[u] * 2);
     }
-    w->g0 = put(npix * 64 * 2); w->g1 = put(npix * 64 * 2);
+    for (int i = 0; i < 3; ++i) w->g[i] = put(npix * 64 * 2);
     w->bnpart = put(1024L * 512 * 4);
     w->headpart = put(1024L * 7 * 64 * 4);
     w->headsums = put(7 * 64 * 4);
@@ -200,6 +202,11 @@ void make_ws_layout(const Dims& d, WsLayout* w) {
     { const long v = slab_need(d.F, d.L, 1, d.N); if (v > s) s = v; }
     w->slab_floats = s;
     w->slab = put(s * 4);
+    // split-K slabs of the batch-row nn.Linear layers (main stream; the big slab belongs to the weight-gradient stream)
+    long s2 = (long)vae_linear_splitk(d.N, 2 * d.L, d.F) * d.N * 2 * d.L;
+    { const long v = (long)vae_linear_splitk(d.N, d.L, d.F) * d.N * d.L; if (v > s2) s2 = v; }
+    w->slab2_floats = s2;
+    w->slab2 = put(s2 * 4);
     w->dz = put((long)d.N * d.L * 4); w->dmu = put((long)d.N * d.L * 4); w->dlv = put((long)d.N * d.L * 4);
     w->dcat = put((long)d.N * 2 * d.L * 2);
     w->dpre = put((long)d.N * d.F * 2);
@@ -270,8 +277,8 @@ int bn_finalize(const Ctx& c, int bi, int g_idx, int rows, int fold, double coun
 int linear_f32(const Ctx& c, const void* a, const void* wgt, const float* bias, float* out, float* out2, int M, int N, int K,
                int epilogue) {
     const int ns = vae_linear_splitk(M, N, K);
-    if (ns > 1 && (long)ns * M * N <= c.ws.slab_floats)
-        return vae_linear_gemm_splitk(a, wgt, bias, out, out2, (float*)c.at(c.ws.slab), ns, M, N, K, epilogue, c.stream);
+    if (ns > 1 && (long)ns * M * N <= c.ws.slab2_floats)
+        return vae_linear_gemm_splitk(a, wgt, bias, out, out2, (float*)c.at(c.ws.slab2), ns, M, N, K, epilogue, c.stream);
     return vae_linear_gemm(a, wgt, bias, out, out2, nullptr, nullptr, M, N, K, epilogue, c.stream);
 }
 
@@ -442,109 +449,192 @@ extern "C" int vae_model_kl_partials(const vae_model_cfg* cfg, void* workspace, 
 }
 
 // ------------------------------------------------------------------ backward
+// Weight gradients are off the critical path of the backward pass: dgrad(L) -> BatchNorm backward(L-1) -> dgrad(L-1)
+// ... never reads them, only the optimizer does.  With a second stream (cfg->side_stream) every wgrad kernel and its
+// slab fold runs there, beside the main chain, which has many small latency-bound kernels that leave CUs idle.
+// Ordering is by events: the side stream waits for the main stream's producer of dY (fork), the main stream waits
+// for a wgrad before it overwrites a buffer that wgrad still reads (three gradient buffers rotate, so that wait is
+// one to two kernels behind), and every call ends with the main stream waiting for the side stream (join).
+struct Fork {
+    hipStream_t main, side;
+    bool two;
+    hipEvent_t* ev;
+    int n;
+};
+
+static const int N_EVENTS = 64;
+static hipEvent_t* event_pool() {
+    static hipEvent_t pool[16][N_EVENTS];
+    static bool made[16] = {false};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    if (!made[dev]) {
+        for (int i = 0; i < N_EVENTS; ++i)
+            if (hipEventCreateWithFlags(&pool[dev][i], hipEventDisableTiming) != hipSuccess) return nullptr;
+        made[dev] = true;
+    }
+    return pool[dev];
+}
+
+static int fork_init(Fork* f, void* main, void* side) {
+    f->main = (hipStream_t)main;
+    f->two = side != nullptr && side != main;
+    f->side = f->two ? (hipStream_t)side : (hipStream_t)main;
+    f->n = 0;
+    f->ev = f->two ? event_pool() : nullptr;
+    CHECK(!f->two || f->ev, "vae_model_backward: could not create the events that order the two streams");
+    return 0;
+}
+// the side stream may start once everything enqueued on the main stream so far has run
+static int side_after_main(Fork* f) {
+    if (!f->two) return 0;
+    hipEvent_t e = f->ev[f->n++ % N_EVENTS];
+    CHECK(hipEventRecord(e, f->main) == hipSuccess && hipStreamWaitEvent(f->side, e, 0) == hipSuccess, "stream fork failed");
+    return 0;
+}
+// marks the side stream's progress; main_after() makes the main stream wait for it
+static int side_mark(Fork* f, hipEvent_t* out) {
+    *out = nullptr;
+    if (!f->two) return 0;
+    hipEvent_t e = f->ev[f->n++ % N_EVENTS];
+    CHECK(hipEventRecord(e, f->side) == hipSuccess, "stream mark failed");
+    *out = e;
+    return 0;
+}
+static int main_after(Fork* f, hipEvent_t e) {
+    if (!f->two || !e) return 0;
+    CHECK(hipStreamWaitEvent(f->main, e, 0) == hipSuccess, "stream join failed");
+    return 0;
+}
+
 static int wgrad_to(const Ctx& c, const void* P, const void* Q, int M, int N, long K, int ldp, int ldq, int mode, int H,
-                    int W, int taps, int* nsplit_out) {
+                    int W, int taps, int* nsplit_out, void* stream) {
     const int ns = vae_wgrad_ksplit(M, N, taps, K);
     *nsplit_out = ns;
-    return vae_wgrad_gemm(P, Q, (float*)c.at(c.ws.slab), M, N, K, ldp, ldq, mode, H, W, ns, c.stream);
+    return vae_wgrad_gemm(P, Q, (float*)c.at(c.ws.slab), M, N, K, ldp, ldq, mode, H, W, ns, stream);
 }
 
 // 3x3 conv weight gradient into the slab: nine-taps-per-workgroup kernel where it applies
-static int conv3_wgrad_to(const Ctx& c, const void* dy, const void* x, int Co, int Ci, int H, int* nsplit_out) {
+static int conv3_wgrad_to(const Ctx& c, const void* dy, const void* x, int Co, int Ci, int H, int* nsplit_out, void* stream) {
     if (vae_conv3_wgrad_patch_ok(H, H, Ci, Co)) {
         const int ns = vae_conv3_wgrad_patch_ksplit(c.d.N, H, H, Ci, Co);
         *nsplit_out = ns;
-        return vae_conv3_wgrad_patch(dy, x, (float*)c.at(c.ws.slab), c.d.N, H, H, Ci, Co, ns, c.stream);
+        return vae_conv3_wgrad_patch(dy, x, (float*)c.at(c.ws.slab), c.d.N, H, H, Ci, Co, ns, stream);
     }
-    return wgrad_to(c, dy, x, Co, Ci, (long)c.d.N * H * H, Co, Ci, VAE_WGRAD_CONV3, H, H, 9, nsplit_out);
+    return wgrad_to(c, dy, x, Co, Ci, (long)c.d.N * H * H, Co, Ci, VAE_WGRAD_CONV3, H, H, 9, nsplit_out, stream);
 }
 
-// stage 0: head .. fc heads (everything after the encoder); leaves d(encoder output) in g-buffer `cur`
-static int backward_decoder(const Ctx& c, const float* d_recon, const float* recon, const float* mu, const float* logvar,
-                            const float* eps_in, const float* dmu_ext, const float* dlv_ext, float kl_scale) {
+// stage 0: head .. fc heads (everything after the encoder); leaves d(encoder output) in gradient buffer 0
+static int backward_decoder(const Ctx& c, Fork* f, const float* d_recon, const float* recon, const float* mu,
+                            const float* logvar, const float* eps_in, const float* dmu_ext, const float* dlv_ext,
+                            float kl_scale) {
     const Dims& d = c.d;
     const WsLayout& w = c.ws;
     const int s8 = d.S / 8;
-    hipStream_t s = (hipStream_t)c.stream;
+    void* sd = f->side;
     int ns = 1;
     // 1x1 head + bn1
     // [d gamma1 | d beta1] and [d head.weight | d head.bias] are adjacent in the flat layout
     TRY(vae_head_bwd(d_recon, recon, c.at(w.yd[2]), c.coef(10, 0), c.coef(10, 1), c.coef(10, 2), c.coef(10, 3),
-                     c.P(P_HEAD_W), (float*)c.at(w.headpart), c.G(P_BN1_G), c.G(P_HEAD_W), c.at(w.g0), d.N, d.S, d.S,
+                     c.P(P_HEAD_W), (float*)c.at(w.headpart), c.G(P_BN1_G), c.G(P_HEAD_W), c.at(w.g[0]), d.N, d.S, d.S,
                      d.Cout, c.stream));
-    // up1, up2, up3 (u = 2, 1, 0): dy in g0 -> input grad in g1 -> bn backward -> g0 ...
+    // up1, up2, up3 (u = 2, 1, 0): dy in buffer x -> (side: weight grad) ; input grad -> y ; bn backward -> z
+    int x = 0;
+    hipEvent_t w_prev = nullptr;       // the wgrad that reads the buffer the next dgrad overwrites
     for (int u = 2; u >= 0; --u) {
+        const int y = (x + 1) % 3, z = (x + 2) % 3;
         const int hh = s8 << u;    // input grid
         const long Min = (long)d.N * hh * hh;
         const int Ci = DEC_CI[u], Co = DEC_CO[u];
         const void* xin = u == 0 ? c.at(w.h) : c.at(w.ad[u - 1]);
-        TRY(wgrad_to(c, c.at(w.g0), xin, Co, Ci, Min, Co, Ci, VAE_WGRAD_CONVT, hh, hh, 4, &ns));
+        TRY(side_after_main(f));
+        TRY(wgrad_to(c, c.at(w.g[x]), xin, Co, Ci, Min, Co, Ci, VAE_WGRAD_CONVT, hh, hh, 4, &ns, sd));
         // slab [co][tap][ci] -> ConvTranspose2d weight [ci][co][tap]
-        TRY(reduce4((float*)c.at(w.slab), ns, 4L * Co * Ci, 0, c.G(P_UP3_W + 4 * u), Co, 4, Ci, 1, 4, 1, 4L * Co, 0, c.stream));
+        TRY(reduce4((float*)c.at(w.slab), ns, 4L * Co * Ci, 0, c.G(P_UP3_W + 4 * u), Co, 4, Ci, 1, 4, 1, 4L * Co, 0, sd));
+        hipEvent_t w_this;
+        TRY(side_mark(f, &w_this));
         // (the bias in front of a train-mode BatchNorm has an identically zero gradient: its slot is left as it is)
-        TRY(vae_convt2x2_dgrad_gemm(c.at(w.g0), c.pk_at(c.pk.ct_d[u]), c.at(w.g1), d.N, hh, hh, Ci, Co, c.stream));
+        TRY(main_after(f, w_prev));    // buffer y was read by the previous iteration's wgrad
+        TRY(vae_convt2x2_dgrad_gemm(c.at(w.g[x]), c.pk_at(c.pk.ct_d[u]), c.at(w.g[y]), d.N, hh, hh, Ci, Co, c.stream));
+        w_prev = w_this;
         if (u > 0) {
             const int bi = 8 + (u - 1);
-            TRY(vae_bn_act_bwd(c.at(w.g1), c.at(w.yd[u - 1]), c.coef(bi, 0), c.coef(bi, 1), c.coef(bi, 2), c.coef(bi, 3),
-                               (float*)c.at(w.bnpart), c.G(P_BN3_G + 4 * (u - 1)), c.at(w.g0), d.N, hh, hh, DEC_CO[u - 1], 0,
+            TRY(vae_bn_act_bwd(c.at(w.g[y]), c.at(w.yd[u - 1]), c.coef(bi, 0), c.coef(bi, 1), c.coef(bi, 2), c.coef(bi, 3),
+                               (float*)c.at(w.bnpart), c.G(P_BN3_G + 4 * (u - 1)), c.at(w.g[z]), d.N, hh, hh, DEC_CO[u - 1], 0,
                                0.0, nullptr, 0, 0, 0, 0, c.stream));
+            x = z;
+        } else {
+            x = y;
         }
     }
-    // g1 = d h (grad of tanh output) [N][F]
+    // g[x] = d h (grad of tanh output) [N][F]
     const int nr = vae_tanh_bwd_rows(d.N);
-    TRY(vae_tanh_bwd(c.at(w.g1), c.at(w.h), c.at(w.dpre), (float*)c.at(w.colp), d.N, d.F, c.stream));
+    TRY(vae_tanh_bwd(c.at(w.g[x]), c.at(w.h), c.at(w.dpre), (float*)c.at(w.colp), d.N, d.F, c.stream));
     // fc_up.bias grad: column sums, NHWC order -> parameter order via a permuting reduce
     TRY(reduce4((float*)c.at(w.colp), nr, d.F, 0, c.G(P_FC_UP_B), 1, d.hw, 256, 1, 0, 1, d.hw, 0, c.stream));
-    TRY(wgrad_to(c, c.at(w.dpre), c.at(w.zb), d.F, d.L, d.N, d.F, d.L, VAE_WGRAD_PLAIN, 1, 1, 1, &ns));
+    TRY(side_after_main(f));
+    TRY(wgrad_to(c, c.at(w.dpre), c.at(w.zb), d.F, d.L, d.N, d.F, d.L, VAE_WGRAD_PLAIN, 1, 1, 1, &ns, sd));
     // slab [(p, c)][l] -> fc_up.weight [(c, p)][l]
-    TRY(reduce4((float*)c.at(w.slab), ns, (long)d.F * d.L, 0, c.G(P_FC_UP_W), d.hw, 256, d.L, 1, d.L, (long)d.hw * d.L, 1, 0,
-                c.stream));
+    TRY(reduce4((float*)c.at(w.slab), ns, (long)d.F * d.L, 0, c.G(P_FC_UP_W), d.hw, 256, d.L, 1, d.L, (long)d.hw * d.L, 1, 0, sd));
     TRY(linear_f32(c, c.at(w.dpre), c.pk_at(c.pk.up_d), nullptr, (float*)c.at(w.dz), nullptr, d.N, d.L, d.F, VAE_EPI_F32));
     TRY(vae_reparam_kl_bwd((const float*)c.at(w.dz), mu, logvar, eps_in, dmu_ext, dlv_ext, kl_scale, (float*)c.at(w.dmu),
                            (float*)c.at(w.dlv), c.at(w.dcat), (long)d.N * d.L, d.L, c.cfg->seed, c.cfg->step, c.cfg->rank,
                            c.stream));
     TRY(vae_sum_partials((const float*)c.at(w.dmu), d.N, d.L, c.G(P_FC_MU_B), 1.0f, c.stream));
     TRY(vae_sum_partials((const float*)c.at(w.dlv), d.N, d.L, c.G(P_FC_LV_B), 1.0f, c.stream));
-    TRY(wgrad_to(c, c.at(w.dcat), c.at(w.ob[3]), 2 * d.L, d.F, d.N, 2 * d.L, d.F, VAE_WGRAD_PLAIN, 1, 1, 1, &ns));
+    TRY(side_after_main(f));
+    TRY(wgrad_to(c, c.at(w.dcat), c.at(w.ob[3]), 2 * d.L, d.F, d.N, 2 * d.L, d.F, VAE_WGRAD_PLAIN, 1, 1, 1, &ns, sd));
     for (int t = 0; t < 2; ++t)
         // slab rows [t*L, (t+1)*L) x columns (p, c) -> fc weight [l][(c, p)]
         TRY(reduce4((float*)c.at(w.slab), ns, 2L * d.L * d.F, (long)t * d.L * d.F, c.G(t ? P_FC_LV_W : P_FC_MU_W), d.L, d.hw,
-                    256, 1, d.F, 1, d.hw, 0, c.stream));
-    // d(encoder output) [N][F] bf16 -> g0
-    return vae_linear_gemm(c.at(w.dcat), c.pk_at(c.pk.fc_d), nullptr, c.at(w.g0), nullptr, nullptr, nullptr, d.N, d.F,
+                    256, 1, d.F, 1, d.hw, 0, sd));
+    // d(encoder output) [N][F] bf16 -> buffer 0 (its last reader, the first ConvT wgrad, is behind the events waited above)
+    TRY(main_after(f, w_prev));
+    return vae_linear_gemm(c.at(w.dcat), c.pk_at(c.pk.fc_d), nullptr, c.at(w.g[0]), nullptr, nullptr, nullptr, d.N, d.F,
                            2 * d.L, VAE_EPI_BF16, c.stream);
 }
 
-// encoder block b: expects d(block output) in g0, leaves d(block input) in g0 (b > 0)
-static int backward_block(const Ctx& c, int b, const void* const* masks) {
+// encoder block b: expects d(block output) in buffer (3 - b) % 3, leaves d(block input) in the next one.
+// *w_carry: the previous block's last wgrad (it reads the buffer this block's first dgrad overwrites).
+static int backward_block(const Ctx& c, Fork* f, int b, const void* const* masks, hipEvent_t* w_carry) {
     const Dims& d = c.d;
     const WsLayout& w = c.ws;
     const int H = d.S >> b, C = ENC_C[b];
     const long M = (long)d.N * H * H;
+    const int ia = (3 - b) % 3, ib = (ia + 1) % 3, ic = (ia + 2) % 3;
+    void* sd = f->side;
     int ns = 1;
     const double p = c.cfg->p_dropout;
-    // second conv + BN + ReLU + dropout (+ pool)
-    TRY(vae_bn_act_bwd(c.at(w.g0), c.at(w.yb[b]), c.coef(2 * b + 1, 0), c.coef(2 * b + 1, 1), c.coef(2 * b + 1, 2),
-                       c.coef(2 * b + 1, 3), (float*)c.at(w.bnpart), c.G(8 * b + 6), c.at(w.g1), d.N, H, H, C, b < 3, p,
+    // second conv + BN + ReLU + dropout (+ pool): a -> b
+    TRY(vae_bn_act_bwd(c.at(w.g[ia]), c.at(w.yb[b]), c.coef(2 * b + 1, 0), c.coef(2 * b + 1, 1), c.coef(2 * b + 1, 2),
+                       c.coef(2 * b + 1, 3), (float*)c.at(w.bnpart), c.G(8 * b + 6), c.at(w.g[ib]), d.N, H, H, C, b < 3, p,
                        masks ? masks[b] : nullptr, c.cfg->seed, c.cfg->step, VAE_STREAM_DROPOUT0 + b, c.cfg->rank, c.stream));
-    TRY(conv3_wgrad_to(c, c.at(w.g1), c.at(w.aa[b]), C, C, H, &ns));
+    TRY(side_after_main(f));
+    TRY(conv3_wgrad_to(c, c.at(w.g[ib]), c.at(w.aa[b]), C, C, H, &ns, sd));
     // slab [co][tap][ci] -> Conv2d weight [co][ci][tap]
-    TRY(reduce4((float*)c.at(w.slab), ns, 9L * C * C, 0, c.G(8 * b + 4), C, 9, C, 1, 9L * C, 1, 9, 0, c.stream));
-    TRY(vae_conv3x3_gemm(c.at(w.g1), c.pk_at(c.pk.conv_d[2 * b]), nullptr, c.at(w.g0), nullptr, nullptr, d.N, H, H, C, C,
+    TRY(reduce4((float*)c.at(w.slab), ns, 9L * C * C, 0, c.G(8 * b + 4), C, 9, C, 1, 9L * C, 1, 9, 0, sd));
+    hipEvent_t w1;
+    TRY(side_mark(f, &w1));
+    TRY(main_after(f, *w_carry));       // buffer c was read by the previous block's second wgrad
+    TRY(vae_conv3x3_gemm(c.at(w.g[ib]), c.pk_at(c.pk.conv_d[2 * b]), nullptr, c.at(w.g[ic]), nullptr, nullptr, d.N, H, H, C, C,
                          c.stream));
-    // first conv + BN + ReLU
-    TRY(vae_bn_act_bwd(c.at(w.g0), c.at(w.ya[b]), c.coef(2 * b, 0), c.coef(2 * b, 1), c.coef(2 * b, 2), c.coef(2 * b, 3),
-                       (float*)c.at(w.bnpart), c.G(8 * b + 2), c.at(w.g1), d.N, H, H, C, 0, 0.0, nullptr, 0, 0, 0, 0, c.stream));
+    // first conv + BN + ReLU: c -> a
+    TRY(vae_bn_act_bwd(c.at(w.g[ic]), c.at(w.ya[b]), c.coef(2 * b, 0), c.coef(2 * b, 1), c.coef(2 * b, 2), c.coef(2 * b, 3),
+                       (float*)c.at(w.bnpart), c.G(8 * b + 2), c.at(w.g[ia]), d.N, H, H, C, 0, 0.0, nullptr, 0, 0, 0, 0, c.stream));
+    TRY(side_after_main(f));
     if (b == 0) {
-        TRY(wgrad_to(c, c.at(w.g1), c.at(w.x8), C, 64, M, C, 8, VAE_WGRAD_CONV3_C8, H, H, 2, &ns));
+        TRY(wgrad_to(c, c.at(w.g[ia]), c.at(w.x8), C, 64, M, C, 8, VAE_WGRAD_CONV3_C8, H, H, 2, &ns, sd));
         // slab [co][16 taps][8 ch] (taps >= 9, channels >= Cin are padding) -> weight [co][ci][tap]
-        return reduce4((float*)c.at(w.slab), ns, 64L * 128, 0, c.G(0), 64, 16, 8, 1, 9L * d.Cin, 1, 9, 0, c.stream, 9, d.Cin);
+        TRY(reduce4((float*)c.at(w.slab), ns, 64L * 128, 0, c.G(0), 64, 16, 8, 1, 9L * d.Cin, 1, 9, 0, sd, 9, d.Cin));
+        return side_mark(f, w_carry);
     }
     const int Ci = ENC_C[b - 1];
-    TRY(conv3_wgrad_to(c, c.at(w.g1), c.at(w.ob[b - 1]), C, Ci, H, &ns));
-    TRY(reduce4((float*)c.at(w.slab), ns, 9L * C * Ci, 0, c.G(8 * b), C, 9, Ci, 1, 9L * Ci, 1, 9, 0, c.stream));
-    return vae_conv3x3_gemm(c.at(w.g1), c.pk_at(c.pk.conv_d[2 * b - 1]), nullptr, c.at(w.g0), nullptr, nullptr, d.N, H, H, C,
-                            Ci, c.stream);
+    TRY(conv3_wgrad_to(c, c.at(w.g[ia]), c.at(w.ob[b - 1]), C, Ci, H, &ns, sd));
+    TRY(reduce4((float*)c.at(w.slab), ns, 9L * C * Ci, 0, c.G(8 * b), C, 9, Ci, 1, 9L * Ci, 1, 9, 0, sd));
+    TRY(side_mark(f, w_carry));
+    TRY(main_after(f, w1));             // buffer b is still read by this block's first wgrad
+    return vae_conv3x3_gemm(c.at(w.g[ia]), c.pk_at(c.pk.conv_d[2 * b - 1]), nullptr, c.at(w.g[ib]), nullptr, nullptr, d.N, H, H,
+                            C, Ci, c.stream);
 }
 
 extern "C" int vae_model_backward(const vae_model_cfg* cfg, const float* params, const void* wpack, void* workspace,
@@ -557,15 +647,21 @@ extern "C" int vae_model_backward(const vae_model_cfg* cfg, const float* params,
     CHECK(cfg->train, "vae_model_backward: the forward pass must have run in train mode");
     CHECK(stage >= -1 && stage <= 2, "vae_model_backward: stage=%d out of range (-1 all, 0 decoder+latent, 1 conv4+conv3, 2 conv2+conv1)", stage);
     c.params = (float*)params; c.grads = grads; c.wpack = (char*)wpack; c.w = (char*)workspace; c.stream = stream;
+    Fork f;
+    TRY(fork_init(&f, stream, cfg->side_stream));
+    hipEvent_t carry = nullptr;
     if (stage == -1 || stage == 0)
-        TRY(backward_decoder(c, d_recon, recon, mu, logvar, eps_in, dmu_ext, dlv_ext, kl_scale));
+        TRY(backward_decoder(c, &f, d_recon, recon, mu, logvar, eps_in, dmu_ext, dlv_ext, kl_scale));
     if (stage == -1 || stage == 1) {
-        TRY(backward_block(c, 3, keep_masks));
-        TRY(backward_block(c, 2, keep_masks));
+        TRY(backward_block(c, &f, 3, keep_masks, &carry));
+        TRY(backward_block(c, &f, 2, keep_masks, &carry));
     }
     if (stage == -1 || stage == 2) {
-        TRY(backward_block(c, 1, keep_masks));
-        TRY(backward_block(c, 0, keep_masks));
+        TRY(backward_block(c, &f, 1, keep_masks, &carry));
+        TRY(backward_block(c, &f, 0, keep_masks, &carry));
     }
-    return 0;
+    // join: whatever the caller enqueues next on `stream` (all-reduce of this stage, the optimizer) sees every gradient
+    hipEvent_t last;
+    TRY(side_mark(&f, &last));
+    return main_after(&f, last);
 }

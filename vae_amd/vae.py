@@ -108,6 +108,8 @@ class VAEConv(nn.Module):
         self._packed_version = -1
         self._ws_pool = {}
         self._last = None           # state of the most recent forward (for the fused train step)
+        self.use_side_stream = True  # backward runs the weight-gradient kernels on a second stream
+        self._side_stream = None
 
     # ------------------------------------------------------------------ layout helpers
     def _ordered_params(self):
@@ -122,10 +124,16 @@ class VAEConv(nn.Module):
 
     def _cfg(self, batch: int, train: bool, step: Optional[int] = None) -> "_lib.ModelCfg":
         hp = self._hp
+        side = None
+        if train and self.use_side_stream and self.flat_params is not None and self.flat_params.is_cuda:
+            if self._side_stream is None or self._side_stream.device != self.flat_params.device:
+                self._side_stream = torch.cuda.Stream(device=self.flat_params.device)
+            side = self._side_stream.cuda_stream
         return _lib.ModelCfg(batch=batch, in_channels=hp["in_channels"], out_channels=hp["out_channels"],
                              latent=hp["latent_dims"], image_size=hp["image_size"], train=int(train),
                              p_dropout=hp["p_dropout"], seed=int(self.rng_seed),
-                             step=int(self.rng_step if step is None else step) & 0xFFFFFFFF, rank=int(self.rank))
+                             step=int(self.rng_step if step is None else step) & 0xFFFFFFFF, rank=int(self.rank),
+                             side_stream=side)
 
     def _flatten(self, device):
         """Move parameters / running stats into the flat buffers the kernels use (views keep
