@@ -256,21 +256,42 @@ __global__ __launch_bounds__(256, 2) void conv3_patch_tn_kernel(const PatchTN p)
     for (int j = 0; j < FN; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) ssum[j][r] = ssq[j][r] = 0.f;
+    // The accumulator layout gives a lane 4 channels of one pixel: stored directly, a wave-instruction would touch
+    // sixteen 32-byte pieces of sixteen rows.  The tile goes through LDS instead ([pixel][BN] bf16, rows padded by
+    // 16 bytes so the 16 pixel-lanes of a write land on different banks) and leaves as 16 bytes per lane in
+    // whole rows.
+    constexpr int OROW = BN * 2 + 16;
+    static_assert(PT_BM * OROW <= Q_BYTES + DEPTH * B_BYTES, "output tile does not fit the staging buffers");
+    __syncthreads();                     // every wave is done reading the patch and the weight ring
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
-        const int m = m0 + wm * TM + i * 16 + (lane & 15);
+        const int ml = wm * TM + i * 16 + (lane & 15);
+        const int m = m0 + ml;
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
-            const int n = n0 + wn * TN + j * 16 + (lane >> 4) * 4;
-            if (m >= p.M || n >= p.N) continue;
+            const int nl = wn * TN + j * 16 + (lane >> 4) * 4;
             float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                v[r] = acc[i][j][r] + bv[j][r];
-                ssum[j][r] += v[r];
-                ssq[j][r] += v[r] * v[r];
+            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bv[j][r];
+            if (m < p.M && n0 + nl < p.N) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    ssum[j][r] += v[r];
+                    ssq[j][r] += v[r] * v[r];
+                }
             }
-            *(uint2*)(p.out + (long)m * p.N + n) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+            *(uint2*)(smem + ml * OROW + nl * 2) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+        }
+    }
+    __syncthreads();
+    {
+        constexpr int CPR = BN / 8;      // 16-byte chunks per row
+#pragma unroll
+        for (int q = 0; q < PT_BM * CPR / 256; ++q) {
+            const int cidx = q * 256 + tid;
+            const int row = cidx / CPR, ch = cidx % CPR;
+            const int m = m0 + row, n = n0 + ch * 8;
+            if (m < p.M && n < p.N) *(uint4*)(p.out + (long)m * p.N + n) = *(const uint4*)(smem + row * OROW + ch * 16);
         }
     }
     if (want_stats) {
