@@ -167,6 +167,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="cfg2_1gpu")
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch size")
+    ap.add_argument("--side-stream", action="store_true",
+                    help="run the weight-gradient kernels of the backward pass on a second stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--torch-optimizer", action="store_true", help="torch.optim.AdamW + clip_grad_norm_ instead of the fused kernel")
@@ -199,6 +201,7 @@ def main():
     torch.manual_seed(int(conf.seed))
     model = VAEConv(Cin, 3, Lat, float(conf.p_dropout), S).to(dev).train()
     model.rng_seed, model.rank = int(conf.seed), rank
+    model.use_side_stream = bool(args.side_stream)
     broadcast_state(model)
     if args.torch_optimizer:
         opt = torch.optim.AdamW(model.parameters(), lr=float(conf.lr))

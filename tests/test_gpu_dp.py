@@ -8,17 +8,17 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _make():
+def _make(batch=8, size=16):
     from vae_amd.optim import FlatAdamW
     from vae_amd.train import Config
     from vae_amd.vae import VAEConv
     torch.manual_seed(1337)
-    model = VAEConv(3, 3, 64, 0.1, 16).to("cuda").train()
+    model = VAEConv(3, 3, 64, 0.1, size).to("cuda").train()
     model.rng_seed, model.rank = 1337, 0
     conf = Config(kl_weight=1.0, percep_weight=0.0, recon_loss="l1", lr=1e-3)
     opt = FlatAdamW(model, lr=1e-3)
     g = torch.Generator(device="cuda").manual_seed(77)
-    x = torch.rand(8, 3, 16, 16, device="cuda", generator=g)
+    x = torch.rand(batch, 3, size, size, device="cuda", generator=g)
     return model, conf, opt, x
 
 
@@ -56,6 +56,34 @@ def test_staged_backward_ranges_are_final_when_handed_over():
         assert torch.equal(snaps[stage], whole[a:b]), f"stage {stage} range changed after it was handed over"
     # the three ranges tile the buffer
     assert sorted(ranges)[0][0] == 0 and sorted(ranges)[-1][1] == whole.numel()
+
+
+def test_side_stream_backward_gives_the_same_gradients():
+    """weight-gradient kernels on a second stream (event-ordered, three rotating gradient buffers): bit-identical
+    to the single-stream pass, whole and staged, three times over (a race would show as a difference)"""
+    from vae_amd.train import FusedStep
+    model, conf, opt, x = _make(batch=256, size=32)     # large enough for the two streams to really overlap
+    fs = FusedStep(model, opt, conf, None)
+    state, d_recon = _loss_grad(model, x, fs)
+    assert state["cfg"].side_stream is None
+    model.backward_raw(state, d_recon, None, None, 1.0 / x.size(0), -1)
+    torch.cuda.synchronize()
+    ref = model.flat_grads.clone()
+    side = torch.cuda.Stream()
+    state["cfg"].side_stream = side.cuda_stream
+    for rep in range(3):
+        model.flat_grads.zero_()
+        if rep == 1:
+            for stage in (0, 1, 2):
+                model.backward_raw(state, d_recon, None, None, 1.0 / x.size(0), stage)
+        else:
+            model.backward_raw(state, d_recon, None, None, 1.0 / x.size(0), -1)
+        torch.cuda.synchronize()
+        assert torch.equal(model.flat_grads, ref), f"repetition {rep}"
+    model._release_workspace(state["batch"], state["ws"])
+    # and through the module switch
+    model.use_side_stream = True
+    assert model._cfg(8, True).side_stream is not None and model._cfg(8, False).side_stream is None
 
 
 class _RecordingReducer:
