@@ -48,6 +48,16 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
     return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
 }
 
+// Workgroup barrier for kernels that keep global->LDS copies (buffer_load ... lds) in flight across it.
+// __syncthreads() carries a workgroup release fence, and because those copies write LDS the compiler
+// turns the fence into s_waitcnt vmcnt(0): every barrier would drain the whole copy ring.  Here the caller
+// has already waited (counted vmcnt) for exactly the copies the next phase reads; the wave's own LDS
+// reads and writes are finished by lgkmcnt(0); the "memory" clobber keeps the compiler from moving
+// memory operations across.
+__device__ __forceinline__ void barrier_keep_copies() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // ---------------------------------------------------------------- reductions (wave = 64)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void conv3_patch_tn_kernel(const PatchTN p)
     float* red = (float*)(smem + Q_BYTES + DEPTH * B_BYTES);
     for (int i = tid; i < 2 * WAVES_M * BN; i += 256) red[i] = 0.f;     // first read is many barriers away
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    if (tile != (int)blockIdx.x) __syncthreads();  // the previous tile's patch and weight tiles are done with
+    if (tile != (int)blockIdx.x) barrier_keep_copies();  // the previous tile's patch and weight tiles are done with
     m0 = tile * PT_BM;
     h0 = p.G == 1 ? ((m0 >> p.wshift) & (p.H - 1)) : 0;
     f32x4 acc[FM][FN];
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void conv3_patch_tn_kernel(const PatchTN p)
             const int left = nsteps - 1 - (9 * c + tap);
             if (tap == 0 && c > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else pt_wait_groups<B_INSTR>(left < DEPTH - 2 ? left : DEPTH - 2);
-            __syncthreads();
+            barrier_keep_copies();
             {   // refill the slot read in the previous K-step with the tile of K-step s + DEPTH - 1
                 const int t2 = tap + DEPTH - 1;
                 const int tapn = t2 >= 9 ? t2 - 9 : t2, cn = t2 >= 9 ? c + 1 : c;
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void conv3_patch_tn_kernel(const PatchTN p)
             slot = slot + 1 == DEPTH ? 0 : slot + 1;
         }
         if (c + 1 < nchunk) {
-            __syncthreads();            // every wave has read the last tap of this chunk's patch
+            barrier_keep_copies();            // every wave has read the last tap of this chunk's patch
             stage_patch(c0 + 64);
         }
     }
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void conv3_patch_tn_kernel(const PatchTN p)
     // whole rows.
     constexpr int OROW = BN * 2 + 16;
     static_assert(PT_BM * OROW <= Q_BYTES + DEPTH * B_BYTES, "output tile does not fit the staging buffers");
-    __syncthreads();                     // every wave is done reading the patch and the weight ring
+    barrier_keep_copies();                     // every wave is done reading the patch and the weight ring
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         const int ml = wm * TM + i * 16 + (lane & 15);
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void conv3_patch_tn_kernel(const PatchTN p)
             *(uint2*)(smem + ml * OROW + nl * 2) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
         }
     }
-    __syncthreads();
+    barrier_keep_copies();
     {
         constexpr int CPR = BN / 8;      // 16-byte chunks per row
 #pragma unroll
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void conv3_patch_tn_kernel(const PatchTN p)
     }   // tile loop
 
     if (want_stats) {
-        __syncthreads();
+        barrier_keep_copies();
         if (tid < BN && n0 + tid < p.N) {
             float s = 0.f, q = 0.f;
 #pragma unroll

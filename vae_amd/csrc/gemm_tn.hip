@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
     int slot = 0;                     // ring slot of K-step ks
     for (int ks = 0; ks < nk; ++ks) {
         wait_vm_groups<A_INSTR + B_INSTR>(min(NST - 2, nk - 1 - ks));   // everything up to K-step ks has landed
-        __syncthreads();
+        barrier_keep_copies();            // not __syncthreads(): its fence would drain the younger copies too
         const unsigned char* abase = smem + slot * STAGE;
         const unsigned char* bbase = abase + A_BYTES;
         // all fragments of this K-step are requested up front, the next tile's global->LDS copies are
