@@ -66,8 +66,11 @@ __device__ __forceinline__ float pt_row16_sum(float v) {
     return v;
 }
 
+// workgroups that share a CU: three of the 64-channel form (a third of the LDS and at most 168 VGPRs each), else two
+constexpr int pt_wgs(int W, int BN) { return BN == 64 && W != 4 ? 3 : 2; }
+
 template <int W, int BN>
-__global__ __launch_bounds__(256, 2) void conv3_patch_tn_kernel(const PatchTN p) {
+__global__ __launch_bounds__(256, pt_wgs(W, BN)) void conv3_patch_tn_kernel(const PatchTN p) {
     constexpr int W2 = W + 2;
     constexpr int WAVES_M = BN == 128 ? 2 : 4, WAVES_N = 4 / WAVES_M;
     constexpr int TM = PT_BM / WAVES_M, TN = BN / WAVES_N;      // wave tile: TM pixels x TN channels
@@ -75,15 +78,17 @@ __global__ __launch_bounds__(256, 2) void conv3_patch_tn_kernel(const PatchTN p)
     constexpr int Q_BYTES = pt_rows(W) * PT_ROWB, B_BYTES = BN * PT_ROWB;
     constexpr int B_INSTR = BN / 8 / 4;
     constexpr int Q_INSTR = (pt_rows(W) / 8 + 3) / 4;           // patch copies per wave
-    // weight tiles sit in a ring as deep as lets two workgroups share a CU (80 KB each), at most 4
-    constexpr int DEPTH = (81920 - 2048 - Q_BYTES) / B_BYTES >= 4 ? 4 : (81920 - 2048 - Q_BYTES) / B_BYTES;
+    // weight tiles sit in a ring as deep as the workgroup's share of the CU's 160 KB allows, at most 4
+    constexpr int LDS_SHARE = (163840 / pt_wgs(W, BN)) / 1280 * 1280;     // whole allocation granules
+    constexpr int DEPTH = (LDS_SHARE - 2048 - Q_BYTES) / B_BYTES >= 4 ? 4 : (LDS_SHARE - 2048 - Q_BYTES) / B_BYTES;
     static_assert(TN == 64, "wave tile is 64 channels wide");
     static_assert(DEPTH >= 2, "ring depth");
 
     constexpr int RED_BYTES = 2 * WAVES_M * BN * 4;                // statistics accumulators
     __shared__ __attribute__((aligned(16))) unsigned char smem[Q_BYTES + DEPTH * B_BYTES + RED_BYTES];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: addresses and branches built on it stay scalar
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int n0 = blockIdx.y * BN;
     int m0 = 0, h0 = 0;          // first pixel of the current tile and its image row (set per tile below)
@@ -358,10 +363,10 @@ static int pt_pick_bn(long M, int Cout) {
     return Cout % 128 == 0 && ntiles * (Cout / 128) >= 256 ? 128 : 64;
 }
 
-int conv3_patch_tn_rows(long M, int Cout) {
+int conv3_patch_tn_rows(long M, int Cout, int W) {
     const long ntiles = (M + PT_BM - 1) / PT_BM;
-    const int gy = Cout / pt_pick_bn(M, Cout);
-    long gx = 512 / gy;                      // two resident workgroups per CU
+    const int bn = pt_pick_bn(M, Cout), gy = Cout / bn;
+    long gx = 256 * pt_wgs(W, bn) / gy;      // every CU holds its full share of resident workgroups
     if (gx > ntiles) gx = ntiles;
     if (gx < 1) gx = 1;
     return (int)gx;
@@ -380,7 +385,7 @@ int conv3_patch_tn_launch(const void* x, const void* w_packed, const float* bias
     p.inv_per = 1.0f / (float)((p.R + 2) * (W + 2));
     VAE_CHECK(p.PR <= pt_rows(W) && p.rwshift >= 0, "conv3 patch kernel: internal geometry error (PR=%d)", p.PR);
     const int bn = pt_pick_bn(p.M, Cout);
-    dim3 grid(conv3_patch_tn_rows(p.M, Cout), Cout / bn);
+    dim3 grid(conv3_patch_tn_rows(p.M, Cout, W), Cout / bn);
     static char name[2][48] = {"conv3_patch_tn_kernel<64>", "conv3_patch_tn_kernel<128>"};
     ProfScope prof(name[bn == 128], flops, bytes, s);
     switch (W) {

@@ -79,7 +79,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNT p) {
 
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: addresses and branches built on it stay scalar
     const int wn = wave & 1, wm = wave >> 1;
     const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
     const int tap = blockIdx.z % p.taps, split = blockIdx.z / p.taps;

@@ -73,7 +73,8 @@ __global__ __launch_bounds__(512, 1) void conv3_wgrad_patch_kernel(const PatchP 
     constexpr int SMEM_BYTES = 4 * STAGE > FOLD_BYTES ? 4 * STAGE : FOLD_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
 
-    const int tid = threadIdx.x, lane = tid & 63, grp = tid >> 8, wave = (tid >> 6) & 3;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int grp = __builtin_amdgcn_readfirstlane(tid >> 8), wave = __builtin_amdgcn_readfirstlane((tid >> 6) & 3);   // wave-uniform
     const int n0 = blockIdx.x * 64, m0 = blockIdx.y * 64, split = blockIdx.z;
     const int kt_beg = split * p.kps + grp, kt_end = min(split * p.kps + p.kps, p.ktiles);   // this group's tiles: stride 2
     const bf16_t* zero = (const bf16_t*)g_zero_page;

@@ -29,7 +29,7 @@ namespace vae {
 
 // conv3_patch_tn.hip
 bool conv3_patch_tn_ok(int n_img, int H, int W, int Cin, int Cout);
-int conv3_patch_tn_rows(long M, int Cout);
+int conv3_patch_tn_rows(long M, int Cout, int W);
 int conv3_patch_tn_launch(const void* x, const void* w_packed, const float* bias, void* y, float* stat_sum, float* stat_sq,
                           int n_img, int H, int W, int Cin, int Cout, double flops, double bytes, hipStream_t s);
 
@@ -113,7 +113,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
 
     __shared__ __attribute__((aligned(16))) unsigned char smem[NST * STAGE];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: addresses and branches built on it stay scalar
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
 
@@ -419,7 +420,7 @@ extern "C" int vae_gemm_stat_rows(long M, int N) {
 
 extern "C" int vae_conv3x3_stat_rows(int n_img, int H, int W, int Cin, int Cout) {
     const long M = (long)n_img * H * W;
-    if (conv3_patch_tn_ok(n_img, H, W, Cin, Cout)) return conv3_patch_tn_rows(M, Cout);
+    if (conv3_patch_tn_ok(n_img, H, W, Cin, Cout)) return conv3_patch_tn_rows(M, Cout, W);
     return vae_gemm_stat_rows(M, Cout);
 }
 
