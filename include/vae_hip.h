@@ -79,7 +79,8 @@ int vae_reparam_kl_bwd(const float* dz, const float* mu, const float* logvar, co
                        float* dlv, void* dcat_bf16, long n_elems, int latent,
                        unsigned long long seed, unsigned step, unsigned rank, void* stream);
 /* raw streams, for RNG parity checks.  mode 0: uint32 words, 1: fp32 normals, 2: uint8 keep-mask
- * with drop probability p_drop.  (torch.randn_like vae.py:110 / nn.Dropout vae.py:137) */
+ * with drop probability p_drop (16-bit draws, 8 elements per Philox block; kept iff draw >=
+ * vae_dropout_threshold(p) = ceil(p * 2^16)).  (torch.randn_like vae.py:110 / nn.Dropout vae.py:137) */
 int vae_philox_fill(void* out, long n, int mode, double p_drop, unsigned long long seed,
                     unsigned step, unsigned stream_id, unsigned rank, void* stream);
 unsigned vae_dropout_threshold(double p_drop);

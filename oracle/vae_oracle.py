@@ -399,13 +399,16 @@ def philox_bits(n: int, seed: int, stream: int, step: int, rank: int = 0) -> np.
 
 
 def dropout_threshold(p: float) -> int:
-    """keep iff (bits >> 8) >= ceil(p * 2^24)  (P(keep) = 1 - thr/2^24)."""
-    return int(math.ceil(p * 16777216.0))
+    """keep iff the element's 16-bit draw >= ceil(p * 2^16)  (P(keep) = 1 - thr/2^16)."""
+    return int(math.ceil(p * 65536.0))
 
 
 def philox_keep_mask(n: int, p: float, seed: int, stream: int, step: int, rank: int = 0) -> np.ndarray:
-    bits = philox_bits(n, seed, stream, step, rank)
-    return ((bits >> np.uint32(8)) >= np.uint32(dropout_threshold(p))).astype(np.uint8)
+    """Element i draws 16 bits: half (i & 1) of word (i >> 1) & 3 of Philox block i >> 3, i.e. the
+    32-bit stream word i >> 1 split low half first (one Philox block serves 8 elements)."""
+    words = philox_bits((n + 1) // 2, seed, stream, step, rank)
+    halves = np.stack([words & np.uint32(0xFFFF), words >> np.uint32(16)], axis=-1).reshape(-1)[:n]
+    return (halves >= np.uint32(dropout_threshold(p))).astype(np.uint8)
 
 
 # fp32-only Box-Muller built from individually rounded +,*,/ and sqrt (no fma,

@@ -30,7 +30,7 @@ def test_stream_layout():
 def test_keep_mask_rate():
     m = O.philox_keep_mask(1 << 20, 0.1, 1337, 0, 0)
     assert abs(m.mean() - 0.9) < 2e-3
-    assert O.dropout_threshold(0.1) == 1677722
+    assert O.dropout_threshold(0.1) == 6554
 
 
 def test_normal_moments_and_accuracy():

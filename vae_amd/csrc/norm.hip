@@ -48,13 +48,14 @@ __device__ __forceinline__ void keep8(const DropCfg& d, long idx0, bool keep[8])
             keep[4 + i] = (m.y >> (8 * i)) & 0xFF;
         }
     } else {
+        // one Philox block serves 8 elements: element i takes the 16-bit half (i & 1) of word (i >> 1)
         uint32_t w[4];
-        philox_block(d.key, (uint32_t)(idx0 >> 2), w);
+        philox_block(d.key, (uint32_t)(idx0 >> 3), w);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) keep[i] = (w[i] >> 8) >= d.thr;
-        philox_block(d.key, (uint32_t)(idx0 >> 2) + 1u, w);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) keep[4 + i] = (w[i] >> 8) >= d.thr;
+        for (int i = 0; i < 4; ++i) {
+            keep[2 * i] = (w[i] & 0xFFFFu) >= d.thr;
+            keep[2 * i + 1] = (w[i] >> 16) >= d.thr;
+        }
     }
 }
 

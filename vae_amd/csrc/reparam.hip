@@ -123,15 +123,21 @@ __global__ __launch_bounds__(256) void reparam_kl_bwd_kernel(
     }
 }
 
-// MODE 0: raw uint32 words, 1: normals (fp32), 2: keep-mask bytes ((word >> 8) >= thr)
+// MODE 0: raw uint32 words, 1: normals (fp32), 2: keep-mask bytes (8 per Philox block: element i of the
+// stream takes the 16-bit half (i & 1) of word (i >> 1) & 3 of block i >> 3, kept iff half >= thr)
 template <int MODE>
 __global__ __launch_bounds__(256) void philox_fill_kernel(void* __restrict__ out, long n,
                                                           PhiloxKey key, uint32_t thr) {
-    const long nblk = (n + 3) >> 2;
+    const long nblk = MODE == 2 ? (n + 7) >> 3 : (n + 3) >> 2;
     for (long b = (long)blockIdx.x * blockDim.x + threadIdx.x; b < nblk;
          b += (long)gridDim.x * blockDim.x) {
-        const long i0 = b << 2;
-        if (MODE == 1) {
+        const long i0 = MODE == 2 ? b << 3 : b << 2;
+        if (MODE == 2) {
+            uint32_t w[4];
+            philox_block(key, (uint32_t)b, w);
+            for (int j = 0; j < 8 && i0 + j < n; ++j)
+                ((uint8_t*)out)[i0 + j] = ((w[j >> 1] >> (16 * (j & 1))) & 0xFFFFu) >= thr ? 1 : 0;
+        } else if (MODE == 1) {
             float z[4];
             philox_normal4(key, (uint32_t)b, z);
             for (int j = 0; j < 4 && i0 + j < n; ++j) ((float*)out)[i0 + j] = z[j];
@@ -139,8 +145,7 @@ __global__ __launch_bounds__(256) void philox_fill_kernel(void* __restrict__ out
             uint32_t w[4];
             philox_block(key, (uint32_t)b, w);
             for (int j = 0; j < 4 && i0 + j < n; ++j) {
-                if (MODE == 0) ((uint32_t*)out)[i0 + j] = w[j];
-                else ((uint8_t*)out)[i0 + j] = (w[j] >> 8) >= thr ? 1 : 0;
+                ((uint32_t*)out)[i0 + j] = w[j];
             }
         }
     }
@@ -211,10 +216,10 @@ extern "C" int vae_philox_fill(void* out, long n, int mode, double p_drop, unsig
 }
 
 extern "C" unsigned vae_dropout_threshold(double p_drop) {
-    double t = p_drop * 16777216.0;
+    double t = p_drop * 65536.0;               // 16-bit draws: P(keep) = 1 - thr / 2^16
     double c = (double)(unsigned long long)t;
     if (c < t) c += 1.0;
-    if (c > 16777216.0) c = 16777216.0;
+    if (c > 65536.0) c = 65536.0;
     if (c < 0) c = 0;
     return (unsigned)c;
 }
