@@ -200,6 +200,14 @@ int vae_bn_act_fwd(const void* y, const float* scale, const float* shift, void* 
                    int H, int W, int C, int pool, double p_drop, const void* keep_mask,
                    unsigned long long seed, unsigned step, unsigned stream_id, unsigned rank,
                    void* stream);
+/* The same with a route record for the pooled form (nn.MaxPool2d(2) after nn.Dropout, vae.py:35-41,137):
+ * route [n,H/2,W/2,C] uint8, one byte per pooled element -- bits 0-1 the window position (scan order,
+ * first maximum wins) of the maximum, bit 2 set when the maximum is positive, i.e. when a gradient flows
+ * through it.  route may be null (nothing is recorded); it must be null when pool == 0. */
+int vae_bn_act_fwd_route(const void* y, const float* scale, const float* shift, void* out, void* route,
+                         int n_img, int H, int W, int C, int pool, double p_drop, const void* keep_mask,
+                         unsigned long long seed, unsigned step, unsigned stream_id, unsigned rank,
+                         void* stream);
 /* rows of the `partial` workspace (x 2*C floats) used by vae_bn_act_bwd */
 int vae_bn_act_bwd_blocks(int n_img, int H, int W, int C, int pool);
 /* backward of the above down to the conv output: gin = grad of the (pooled) block output,
@@ -209,6 +217,13 @@ int vae_bn_act_bwd(const void* gin, const void* y, const float* scale, const flo
                    int n_img, int H, int W, int C, int pool, double p_drop, const void* keep_mask,
                    unsigned long long seed, unsigned step, unsigned stream_id, unsigned rank,
                    void* stream);
+/* The same reading the route bytes vae_bn_act_fwd_route left (pooled form): no dropout stream is
+ * regenerated and no activation recomputed; with route == null it is vae_bn_act_bwd. */
+int vae_bn_act_bwd_route(const void* gin, const void* y, const float* scale, const float* shift,
+                         const float* mean, const float* rstd, float* partial, float* sums, void* dy,
+                         const void* route, int n_img, int H, int W, int C, int pool, double p_drop,
+                         const void* keep_mask, unsigned long long seed, unsigned step,
+                         unsigned stream_id, unsigned rank, void* stream);
 /* relu(bn1(.)) -> nn.Conv2d(64, Cout, 1) -> sigmoid, vae/models/vae.py:74,121-122.
  * y [n,H,W,64] bf16, w [Cout][64] f32, recon [n,Cout,H,W] f32 (NCHW, the module output). */
 int vae_head_fwd(const void* y, const float* scale, const float* shift, const float* w,

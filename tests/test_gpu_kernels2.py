@@ -225,6 +225,36 @@ def test_bn_act_fwd_bwd(L, n, H, W, C, pool, p, inject):
     assert rel_l2(sums[:C].cpu(), gr.grad) <= 2e-5
     assert rel_l2(sums[C:].cpu(), br.grad) <= 2e-5
     check_bf16(from_nhwc(dy), yr.grad, "bn_act bwd", rtol=4e-3)
+    if not pool:
+        with pytest.raises(RuntimeError, match="route bytes exist only for the pooled form"):
+            L.call("vae_bn_act_fwd_route", L.ptr(yd), L.ptr(sc), L.ptr(sh), L.ptr(out), L.ptr(partial), n, H, W, C, pool, p,
+                   L.ptr(md), seed, step, stream_id, rank, L.current_stream())
+        return
+    # ---- the routed pair: the forward records which window element won and whether a gradient flows
+    # through it, the backward reads that instead of regenerating the dropout stream
+    route = torch.full((n, H // 2, W // 2, C), 255, device=DEV, dtype=torch.uint8)
+    out2 = torch.full_like(out, float("nan"))
+    L.call("vae_bn_act_fwd_route", L.ptr(yd), L.ptr(sc), L.ptr(sh), L.ptr(out2), L.ptr(route), n, H, W, C, pool, p,
+           L.ptr(md), seed, step, stream_id, rank, L.current_stream())
+    assert torch.equal(out2, out)
+    # expected route from the oracle's activation: first maximum in scan order, live iff it is positive
+    win = a.detach().unfold(2, 2, 2).unfold(3, 2, 2).reshape(n, C, H // 2, W // 2, 4)
+    live_ref = (win.max(-1).values > 0).permute(0, 2, 3, 1)
+    r = route.cpu()
+    assert int(r.max()) <= 7
+    # ties and bf16-rounded activations can move the winner between equal values: the flag must match exactly,
+    # the position must select a maximal element
+    assert torch.equal((r >> 2).bool(), live_ref)
+    picked = torch.gather(win, 4, (r & 3).permute(0, 3, 1, 2).long().unsqueeze(-1)).squeeze(-1)
+    assert torch.allclose(picked, win.max(-1).values, rtol=1e-2, atol=1e-3)
+    partial.fill_(float("nan")); sums2 = torch.full_like(sums, float("nan")); dy2 = torch.full_like(dy, float("nan"))
+    L.call("vae_bn_act_bwd_route", L.ptr(gind), L.ptr(yd), L.ptr(sc), L.ptr(sh), L.ptr(mean), L.ptr(rstd), L.ptr(partial),
+           L.ptr(sums2), L.ptr(dy2), L.ptr(route), n, H, W, C, pool, p, L.ptr(md), seed, step, stream_id, rank,
+           L.current_stream())
+    assert rel_l2(sums2[:C].cpu(), gr.grad) <= 2e-5
+    assert rel_l2(sums2[C:].cpu(), br.grad) <= 2e-5
+    check_bf16(from_nhwc(dy2), yr.grad, "bn_act bwd (routed)", rtol=4e-3)
+    assert rel_l2(dy2.float().cpu(), dy.float().cpu()) <= 3e-3      # same result as the recomputing form, to bf16 rounding
 
 
 def test_bn_finalize_eval_and_fold(L):

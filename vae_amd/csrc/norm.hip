@@ -203,10 +203,14 @@ __device__ __forceinline__ void split_pooled(const ActGeom& g, unsigned pos, int
     }
 }
 
+// POOL with `route`: one byte per pooled element records what the backward pass needs to know about the window --
+// bits 0-1 the position (scan order, first maximum wins) of the maximum, bit 2 set when that maximum is positive
+// (the element was kept by dropout and passed the ReLU, so the gradient flows) -- so the backward kernels neither
+// regenerate the dropout stream nor redo the activation of the four window elements.
 template <bool POOL>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16_t* __restrict__ y, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, bf16_t* __restrict__ out,
-                                                         ActGeom g, DropCfg d) {
+                                                         uint8_t* __restrict__ route, ActGeom g, DropCfg d) {
     const int cgs = g.C >> 3;
     const long npos = POOL ? (long)g.n_img * (g.H >> 1) * (g.W >> 1) : (long)g.n_img * g.H * g.W;
     // cgs is a power of two dividing 256: a thread keeps its channel group, positions advance by a fixed stride
@@ -227,8 +231,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16_t* __restric
             int wo, ho;
             long img;
             split_pooled(g, pos, wo, ho, img);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) o[i] = -INFINITY;
+            uint32_t arg[8];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const long pix = (img * g.H + 2 * ho + (k >> 1)) * g.W + 2 * wo + (k & 1);
@@ -236,7 +239,17 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16_t* __restric
                 load8(y + pix * g.C + c0, v);
                 act8(v, sc, sh, d, pix * g.C + c0, a, ps, kp);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) o[i] = fmaxf(o[i], a[i]);
+                for (int i = 0; i < 8; ++i) {
+                    if (k == 0) { o[i] = a[i]; arg[i] = 0; }
+                    else if (a[i] > o[i]) { o[i] = a[i]; arg[i] = k; }       // strict >: the first maximum wins, as in MaxPool2d
+                }
+            }
+            if (route) {
+                uint32_t r[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) r[i] = arg[i] | (o[i] > 0.f ? 4u : 0u);
+                *(uint2*)(route + (long)pos * g.C + c0) = make_uint2(r[0] | (r[1] << 8) | (r[2] << 16) | (r[3] << 24),
+                                                                      r[4] | (r[5] << 8) | (r[6] << 16) | (r[7] << 24));
             }
         }
         store8(out + (long)pos * g.C + c0, o);
@@ -244,13 +257,14 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16_t* __restric
 }
 
 // PASS 0: reduce sum(g*xhat), sum(g) per channel into partial[block][2][C];  PASS 1: write dy.
-template <bool POOL, int PASS>
+// ROUTED (POOL only): the forward pass left one route byte per pooled element (see bn_act_fwd_kernel).
+template <bool POOL, int PASS, bool ROUTED>
 __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const bf16_t* __restrict__ gin, const bf16_t* __restrict__ y,
                                                          const float* __restrict__ scale, const float* __restrict__ shift,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          const float* __restrict__ sums, float inv_count,
                                                          float* __restrict__ partial, bf16_t* __restrict__ dy,
-                                                         ActGeom g, DropCfg d) {
+                                                         const uint8_t* __restrict__ route, ActGeom g, DropCfg d) {
     __shared__ float red[2][256][8];
     const int cgs = g.C >> 3;
     const long npos = POOL ? (long)g.n_img * (g.H >> 1) * (g.W >> 1) : (long)g.n_img * g.H * g.W;
@@ -292,6 +306,39 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const bf16_t* __restric
                 else o[i] = sc[i] * (gg - c1[i] - xh * c2[i]);
             }
             if (PASS == 1) store8(dy + pos * g.C + c0, o);
+        } else if (ROUTED) {
+            int wo, ho;
+            long img;
+            split_pooled(g, up, wo, ho, img);
+            const uint2 rr = *(const uint2*)(route + pos * g.C + c0);
+            float v[4][8];
+            long pix[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                pix[k] = (img * g.H + 2 * ho + (k >> 1)) * g.W + 2 * wo + (k & 1);
+                load8(y + pix[k] * g.C + c0, v[k]);
+            }
+            const float ik = d.enabled ? d.inv_keep : 1.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const uint32_t r = ((i < 4 ? rr.x : rr.y) >> (8 * (i & 3))) & 0xFFu;
+                const uint32_t arg = r & 3u;
+                const float gg = (r & 4u) ? gi[i] * ik : 0.f;          // gradient arriving at the window's maximum
+                if (PASS == 0) {
+                    const float vs = arg == 0 ? v[0][i] : arg == 1 ? v[1][i] : arg == 2 ? v[2][i] : v[3][i];
+                    a_gx[i] += gg * ((vs - mu[i]) * rs[i]);
+                    a_g[i] += gg;
+                } else {
+                    // dx = sc * (g - c1 - xhat * c2): the g term only at the maximum
+                    const float a0 = -sc[i] * c1[i], b0 = -sc[i] * c2[i] * rs[i], sg = sc[i] * gg;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k][i] = (v[k][i] - mu[i]) * b0 + a0 + (arg == (uint32_t)k ? sg : 0.f);
+                }
+            }
+            if (PASS == 1) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) store8(dy + pix[k] * g.C + c0, v[k]);
+            }
         } else {
             int wo, ho;
             long img;
@@ -589,7 +636,17 @@ extern "C" int vae_sum_partials(const float* partial, int rows, int ncols, float
 extern "C" int vae_bn_act_fwd(const void* y, const float* scale, const float* shift, void* out, int n_img, int H, int W,
                               int C, int pool, double p_drop, const void* keep_mask, unsigned long long seed,
                               unsigned step, unsigned stream_id, unsigned rank, void* stream) {
+    return vae_bn_act_fwd_route(y, scale, shift, out, nullptr, n_img, H, W, C, pool, p_drop, keep_mask, seed, step,
+                                stream_id, rank, stream);
+}
+
+extern "C" int vae_bn_act_fwd_route(const void* y, const float* scale, const float* shift, void* out, void* route,
+                                    int n_img, int H, int W, int C, int pool, double p_drop, const void* keep_mask,
+                                    unsigned long long seed, unsigned step, unsigned stream_id, unsigned rank,
+                                    void* stream) {
     VAE_CHECK(y && scale && shift && out, "vae_bn_act_fwd: null pointer");
+    VAE_CHECK(!route || pool, "vae_bn_act_fwd_route: route bytes exist only for the pooled form");
+    VAE_CHECK(((uintptr_t)route & 7) == 0, "vae_bn_act_fwd_route: route must be 8-byte aligned");
     if (int e = check_geom("vae_bn_act_fwd", n_img, H, W, C, pool)) return e;
     VAE_CHECK(p_drop >= 0.0 && p_drop < 1.0, "vae_bn_act_fwd: p_drop=%f out of [0,1)", p_drop);
     ActGeom g = {n_img, H, W, C, pool, pow2_shift(W >> 1), pow2_shift(H >> 1)};
@@ -598,8 +655,8 @@ extern "C" int vae_bn_act_fwd(const void* y, const float* scale, const float* sh
     hipStream_t s = (hipStream_t)stream;
     const double elems = (double)n_img * H * W * C;
     ProfScope prof(pool ? "bn_act_fwd_kernel<pool>" : "bn_act_fwd_kernel", 0.0, 2.0 * elems * (pool ? 1.25 : 2.0), s);
-    if (pool) hipLaunchKernelGGL(bn_act_fwd_kernel<true>, dim3(elem_grid(items)), dim3(256), 0, s, (const bf16_t*)y, scale, shift, (bf16_t*)out, g, d);
-    else hipLaunchKernelGGL(bn_act_fwd_kernel<false>, dim3(elem_grid(items)), dim3(256), 0, s, (const bf16_t*)y, scale, shift, (bf16_t*)out, g, d);
+    if (pool) hipLaunchKernelGGL(bn_act_fwd_kernel<true>, dim3(elem_grid(items)), dim3(256), 0, s, (const bf16_t*)y, scale, shift, (bf16_t*)out, (uint8_t*)route, g, d);
+    else hipLaunchKernelGGL(bn_act_fwd_kernel<false>, dim3(elem_grid(items)), dim3(256), 0, s, (const bf16_t*)y, scale, shift, (bf16_t*)out, (uint8_t*)nullptr, g, d);
     VAE_LAUNCH_CHECK("bn_act_fwd_kernel");
     return 0;
 }
@@ -616,7 +673,19 @@ extern "C" int vae_bn_act_bwd(const void* gin, const void* y, const float* scale
                               const float* rstd, float* partial, float* sums, void* dy, int n_img, int H, int W, int C,
                               int pool, double p_drop, const void* keep_mask, unsigned long long seed, unsigned step,
                               unsigned stream_id, unsigned rank, void* stream) {
+    return vae_bn_act_bwd_route(gin, y, scale, shift, mean, rstd, partial, sums, dy, nullptr, n_img, H, W, C, pool, p_drop,
+                                keep_mask, seed, step, stream_id, rank, stream);
+}
+
+extern "C" int vae_bn_act_bwd_route(const void* gin, const void* y, const float* scale, const float* shift,
+                                    const float* mean, const float* rstd, float* partial, float* sums, void* dy,
+                                    const void* route, int n_img, int H, int W, int C, int pool, double p_drop,
+                                    const void* keep_mask, unsigned long long seed, unsigned step, unsigned stream_id,
+                                    unsigned rank, void* stream) {
     VAE_CHECK(gin && y && scale && shift && mean && rstd && partial && sums && dy, "vae_bn_act_bwd: null pointer");
+    VAE_CHECK(!route || pool, "vae_bn_act_bwd_route: route bytes exist only for the pooled form");
+    VAE_CHECK(((uintptr_t)route & 7) == 0, "vae_bn_act_bwd_route: route must be 8-byte aligned");
+    const uint8_t* rt = (const uint8_t*)route;
     if (int e = check_geom("vae_bn_act_bwd", n_img, H, W, C, pool)) return e;
     ActGeom g = {n_img, H, W, C, pool, pow2_shift(W >> 1), pow2_shift(H >> 1)};
     const DropCfg d = make_drop(p_drop, keep_mask, seed, step, stream_id, rank);
@@ -629,14 +698,16 @@ extern "C" int vae_bn_act_bwd(const void* gin, const void* y, const float* scale
     // both passes together: y read twice, gin read twice, dy written once
     ProfScope prof(pool ? "bn_act_bwd(reduce+apply)<pool>" : "bn_act_bwd(reduce+apply)", 0.0,
                    2.0 * elems * (2.0 + 2.0 * (pool ? 0.25 : 1.0) + 1.0), s);
-    if (pool) hipLaunchKernelGGL((bn_act_bwd_kernel<true, 0>), dim3(nb), dim3(256), 0, s, gi, yy, scale, shift, mean, rstd, sums, inv_count, partial, (bf16_t*)dy, g, d);
-    else hipLaunchKernelGGL((bn_act_bwd_kernel<false, 0>), dim3(nb), dim3(256), 0, s, gi, yy, scale, shift, mean, rstd, sums, inv_count, partial, (bf16_t*)dy, g, d);
+    if (pool && rt) hipLaunchKernelGGL((bn_act_bwd_kernel<true, 0, true>), dim3(nb), dim3(256), 0, s, gi, yy, scale, shift, mean, rstd, sums, inv_count, partial, (bf16_t*)dy, rt, g, d);
+    else if (pool) hipLaunchKernelGGL((bn_act_bwd_kernel<true, 0, false>), dim3(nb), dim3(256), 0, s, gi, yy, scale, shift, mean, rstd, sums, inv_count, partial, (bf16_t*)dy, rt, g, d);
+    else hipLaunchKernelGGL((bn_act_bwd_kernel<false, 0, false>), dim3(nb), dim3(256), 0, s, gi, yy, scale, shift, mean, rstd, sums, inv_count, partial, (bf16_t*)dy, rt, g, d);
     VAE_LAUNCH_CHECK("bn_act_bwd_kernel<0>");
     hipLaunchKernelGGL(sum_partials_kernel, dim3((2 * C + 31) / 32), dim3(1024), 0, s, partial, nb, 2 * C, 2 * C, sums, 1.0f);
     VAE_LAUNCH_CHECK("sum_partials_kernel");
     const int nb2 = elem_grid((long)n_img * H * W / (pool ? 4 : 1) * (C / 8));
-    if (pool) hipLaunchKernelGGL((bn_act_bwd_kernel<true, 1>), dim3(nb2), dim3(256), 0, s, gi, yy, scale, shift, mean, rstd, sums, inv_count, partial, (bf16_t*)dy, g, d);
-    else hipLaunchKernelGGL((bn_act_bwd_kernel<false, 1>), dim3(nb2), dim3(256), 0, s, gi, yy, scale, shift, mean, rstd, sums, inv_count, partial, (bf16_t*)dy, g, d);
+    if (pool && rt) hipLaunchKernelGGL((bn_act_bwd_kernel<true, 1, true>), dim3(nb2), dim3(256), 0, s, gi, yy, scale, shift, mean, rstd, sums, inv_count, partial, (bf16_t*)dy, rt, g, d);
+    else if (pool) hipLaunchKernelGGL((bn_act_bwd_kernel<true, 1, false>), dim3(nb2), dim3(256), 0, s, gi, yy, scale, shift, mean, rstd, sums, inv_count, partial, (bf16_t*)dy, rt, g, d);
+    else hipLaunchKernelGGL((bn_act_bwd_kernel<false, 1, false>), dim3(nb2), dim3(256), 0, s, gi, yy, scale, shift, mean, rstd, sums, inv_count, partial, (bf16_t*)dy, rt, g, d);
     VAE_LAUNCH_CHECK("bn_act_bwd_kernel<1>");
     return 0;
 }
