@@ -276,23 +276,47 @@ __global__ __launch_bounds__(256) void reduce_slabs_scatter_kernel(const float* 
     }
 }
 
-// Every weight tensor of the model repacked in ONE launch: blockIdx.y selects the job.
+// Every weight tensor of the model repacked in ONE launch: blockIdx.y selects the job.  A job is walked in the
+// DESTINATION's order (its four dims sorted by destination stride on the host), so the packed operand is written
+// in runs -- 16 bytes per lane when the innermost run is a multiple of 8 bf16 -- and the fp32 source is gathered
+// (strided reads cost a fraction of what scattered 2-byte stores do).
 struct PackJob {
     const float* src;
     void* dst;
-    long n;
-    IndexMap mp;
-    int f32;     // 1: fp32 permuting copy, 0: bf16 pack
+    int n;               // elements
+    int d1, d2, d3;      // sizes of the three inner dims in destination order
+    int ss[4];           // source strides (elements) of the four dims in destination order
+    long ds[4];          // destination strides, ds[3] == 1 when vec8
+    long base;
+    int f32;             // 1: fp32 permuting copy, 0: bf16 pack
+    int vec8;            // innermost destination run is contiguous and a multiple of 8
 };
 struct PackJobs {
     PackJob j[VAE_MAX_PACK_JOBS];
 };
 __global__ __launch_bounds__(256) void multi_pack_kernel(const PackJobs jobs) {
     const PackJob& jb = jobs.j[blockIdx.y];
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < jb.n; e += (long)gridDim.x * blockDim.x) {
-        const long d = map_index(jb.mp, e);
-        if (jb.f32) ((float*)jb.dst)[d] = jb.src[e];
-        else ((bf16_t*)jb.dst)[d] = f2bf(jb.src[e]);
+    const int step = jb.vec8 ? 8 : 1;
+    const int items = jb.n / step;
+    for (int it = blockIdx.x * blockDim.x + threadIdx.x; it < items; it += gridDim.x * blockDim.x) {
+        const unsigned e = (unsigned)it * step;
+        const unsigned i3 = e % (unsigned)jb.d3;
+        unsigned t = e / (unsigned)jb.d3;
+        const unsigned i2 = t % (unsigned)jb.d2;
+        t /= (unsigned)jb.d2;
+        const unsigned i1 = t % (unsigned)jb.d1, i0 = t / (unsigned)jb.d1;
+        const float* s = jb.src + ((long)i0 * jb.ss[0] + (long)i1 * jb.ss[1] + (long)i2 * jb.ss[2] + (long)i3 * jb.ss[3]);
+        const long d = jb.base + i0 * jb.ds[0] + i1 * jb.ds[1] + i2 * jb.ds[2] + i3 * jb.ds[3];
+        if (jb.vec8) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = s[(long)k * jb.ss[3]];
+            *(uint4*)((bf16_t*)jb.dst + d) = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+        } else if (jb.f32) {
+            ((float*)jb.dst)[d] = *s;
+        } else {
+            ((bf16_t*)jb.dst)[d] = f2bf(*s);
+        }
     }
 }
 
@@ -479,18 +503,35 @@ extern "C" int vae_multi_pack(const vae_pack_job* jobs, int njobs, void* stream)
               VAE_MAX_PACK_JOBS);
     PackJobs pj;
     double bytes = 0;
+    int max_items = 1;
     for (int i = 0; i < njobs; ++i) {
         VAE_CHECK(jobs[i].src && jobs[i].dst, "vae_multi_pack: job %d has a null pointer", i);
-        const long dims[4] = {jobs[i].dims[0], jobs[i].dims[1], jobs[i].dims[2], jobs[i].dims[3]};
-        if (int e = make_map(pj.j[i].mp, dims, jobs[i].strides, jobs[i].base, "vae_multi_pack")) return e;
-        pj.j[i].src = jobs[i].src;
-        pj.j[i].dst = jobs[i].dst;
-        pj.j[i].n = dims[0] * dims[1] * dims[2] * dims[3];
-        pj.j[i].f32 = jobs[i].f32;
-        bytes += pj.j[i].n * (jobs[i].f32 ? 8.0 : 6.0);
+        const long* dims = jobs[i].dims;
+        VAE_CHECK(dims[0] > 0 && dims[1] > 0 && dims[2] > 0 && dims[3] > 0, "vae_multi_pack: job %d has bad dims", i);
+        const long n = dims[0] * dims[1] * dims[2] * dims[3];
+        VAE_CHECK(n < (1L << 31), "vae_multi_pack: job %d has 2^31 or more elements", i);
+        // order the dims by destination stride, largest first (size-1 dims first of all: they index nothing)
+        const long sstride[4] = {dims[1] * dims[2] * dims[3], dims[2] * dims[3], dims[3], 1};
+        int ord[4] = {0, 1, 2, 3};
+        auto key = [&](int k) { return dims[k] == 1 ? (1L << 62) : (jobs[i].strides[k] < 0 ? -jobs[i].strides[k] : jobs[i].strides[k]); };
+        for (int a = 0; a < 4; ++a)
+            for (int b = a + 1; b < 4; ++b)
+                if (key(ord[b]) > key(ord[a])) { const int t = ord[a]; ord[a] = ord[b]; ord[b] = t; }
+        PackJob& q = pj.j[i];
+        q.src = jobs[i].src; q.dst = jobs[i].dst; q.n = (int)n; q.f32 = jobs[i].f32; q.base = jobs[i].base;
+        q.d1 = (int)dims[ord[1]]; q.d2 = (int)dims[ord[2]]; q.d3 = (int)dims[ord[3]];
+        for (int k = 0; k < 4; ++k) { q.ss[k] = (int)sstride[ord[k]]; q.ds[k] = jobs[i].strides[ord[k]]; }
+        bool aligned = jobs[i].base % 8 == 0 && ((uintptr_t)jobs[i].dst & 15) == 0;
+        for (int k = 0; k < 3; ++k) aligned = aligned && (dims[ord[k]] == 1 || q.ds[k] % 8 == 0);
+        q.vec8 = !jobs[i].f32 && q.ds[3] == 1 && q.d3 % 8 == 0 && aligned;
+        const int items = (int)(n / (q.vec8 ? 8 : 1));
+        if (items > max_items) max_items = items;
+        bytes += n * (jobs[i].f32 ? 8.0 : 6.0);
     }
+    int gx = (max_items + 255) / 256;
+    if (gx > 128) gx = 128;
     ProfScope prof("multi_pack_kernel", 0.0, bytes, (hipStream_t)stream);
-    hipLaunchKernelGGL(multi_pack_kernel, dim3(64, njobs), dim3(256), 0, (hipStream_t)stream, pj);
+    hipLaunchKernelGGL(multi_pack_kernel, dim3(gx, njobs), dim3(256), 0, (hipStream_t)stream, pj);
     VAE_LAUNCH_CHECK("multi_pack_kernel");
     return 0;
 }
