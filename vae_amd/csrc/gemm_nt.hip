@@ -67,7 +67,18 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* base, int k0, int
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int BM, int BN, int MODE>
+// s_waitcnt vmcnt(groups * PER) for a wave-uniform runtime group count in [0, 3]
+template <int PER>
+__device__ __forceinline__ void nt_wait_groups(int groups) {
+    if (groups <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (groups == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+    else if (groups == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PER) : "memory");
+}
+
+// NST-deep ring of K tiles: the copies of K-step ks + NST - 1 are issued while K-step ks computes.  These problems
+// are short on arithmetic per byte (small M x N, long K), so what matters is how many tiles are in flight.
+template <int BM, int BN, int MODE, int NST>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNT p) {
     constexpr int BK = 64;
     constexpr int ROWP = BM * 2, ROWQ = BN * 2;          // LDS row bytes
@@ -77,7 +88,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNT p) {
     constexpr int TMw = BM / 2, TNw = BN / 2;            // wave tile (2 x 2 waves)
     constexpr int FM = TMw / 16, FN = TNw / 16;
 
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+    static_assert(NST >= 2 && NST <= 5 && (NST - 2) * (P_INSTR + Q_INSTR) <= 63, "ring depth");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NST * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: addresses and branches built on it stay scalar
@@ -158,12 +170,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNT p) {
         for (int j = 0; j < FM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nk = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
-    if (nk > 0) stage(0, kbeg);
+#pragma unroll
+    for (int q = 0; q < NST - 1; ++q)
+        if (q < nk) stage(q, kbeg + q * BK);
+    int slot = 0;
     for (int ks = 0; ks < nk; ++ks) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (ks + 1 < nk) stage((ks + 1) & 1, kbeg + (ks + 1) * BK);
-        const unsigned char* pbase = smem + (ks & 1) * STAGE;
+        nt_wait_groups<P_INSTR + Q_INSTR>(min(NST - 2, nk - 1 - ks));      // K-step ks has landed
+        barrier_keep_copies();            // not __syncthreads(): its fence would drain the younger copies too
+        if (ks + NST - 1 < nk) stage(slot == 0 ? NST - 1 : slot - 1, kbeg + (ks + NST - 1) * BK);   // the slot read in K-step ks - 1
+        const unsigned char* pbase = smem + slot * STAGE;
+        slot = slot + 1 == NST ? 0 : slot + 1;
         const unsigned char* qbase = pbase + P_BYTES;
 #pragma unroll
         for (int kk = 0; kk < BK / 32; ++kk) {
@@ -359,7 +375,14 @@ static int launch_nt(const GemmNT& p, int nsplit, hipStream_t s) {
         static char name[64] = "";                                                            \
         if (!name[0]) snprintf(name, sizeof(name), "gemm_nt_kernel<%d,%d,%d>", BM_, BN_, MODE); \
         ProfScope prof(name, flops, bytes, s);                                                \
-        hipLaunchKernelGGL((gemm_nt_kernel<BM_, BN_, MODE>), grid, block, 0, s, p);           \
+        /* ring depth: what lets two workgroups share a CU's LDS; four when the grid gives a CU one workgroup anyway */ \
+        constexpr int STG = (BM_ + BN_) * 128;                                                \
+        constexpr int NST2 = STG <= 16384 ? 4 : STG <= 24576 ? 3 : 2;                         \
+        constexpr int NST1 = 4;                                                               \
+        if (NST1 != NST2 && (long)grid.x * grid.y * grid.z <= 256)                            \
+            hipLaunchKernelGGL((gemm_nt_kernel<BM_, BN_, MODE, NST1>), grid, block, 0, s, p); \
+        else                                                                                  \
+            hipLaunchKernelGGL((gemm_nt_kernel<BM_, BN_, MODE, NST2>), grid, block, 0, s, p); \
     }
     if (m128 && n128) GO(128, 128)
     else if (m128) GO(128, 64)
@@ -375,12 +398,13 @@ static int launch_nt(const GemmNT& p, int nsplit, hipStream_t s) {
 using namespace vae;
 
 extern "C" int vae_wgrad_ksplit(int M, int N, int taps, long Ktot) {
-    // aim at ~512 workgroups (2 per CU) with at least 1024 k rows each: every split costs one
-    // slab of the whole weight tensor in HBM traffic, so small-K layers get few splits
+    // aim at ~512 workgroups (2 per CU) with at least 256 k rows (four K-steps) each.  A K-step of these
+    // small tiles costs about a memory round trip (~1.5 us) whatever the ring depth, a split costs one slab
+    // of the weight tensor written and read back (~0.1-0.3 us): short K ranges on many CUs win
     const long tm = M % 128 == 0 ? M / 128 : M / 64, tn = N % 128 == 0 ? N / 128 : N / 64;
     const long tiles = tm * tn * taps;
     long s = (512 + tiles - 1) / tiles;
-    const long maxs = (Ktot + 1023) / 1024;
+    const long maxs = (Ktot + 255) / 256;
     if (s > maxs) s = maxs;
     if (s < 1) s = 1;
     if (s > 256) s = 256;
