@@ -351,7 +351,13 @@ static int launch_one(const GemmTN& p, hipStream_t s) {
     static char name[64] = "";
     if (!name[0]) snprintf(name, sizeof(name), "gemm_tn_kernel<%d,%d,%d,%d,%d,%d>", BM, BN, BK, WAVES_M, AMODE, EPI);
     ProfScope prof(name, p.flops, p.bytes, s);
-    if (NST_DEEP != NST && (long)grid.x * grid.y * grid.z <= 256 && p.K / BK >= 8)
+    // one or two K-steps: both tiles are requested up front and nothing is refilled, so a deeper ring only costs LDS --
+    // two stages leave room for a third (or fifth) workgroup per CU, and these launches live on how many
+    // workgroups overlap their load, compute and store phases
+    const int nk = p.ksteps > 0 ? p.ksteps : p.K / BK;
+    if (NST != 2 && nk <= 2)
+        hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, BK, WAVES_M, AMODE, EPI, 2>), grid, dim3(256), 0, s, p);
+    else if (NST_DEEP != NST && (long)grid.x * grid.y * grid.z <= 256 && p.K / BK >= 8)
         hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, BK, WAVES_M, AMODE, EPI, NST_DEEP>), grid, dim3(256), 0, s, p);
     else
         hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, BK, WAVES_M, AMODE, EPI, NST>), grid, dim3(256), 0, s, p);
