@@ -396,7 +396,7 @@ template <int CO>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const bf16_t* __restrict__ y, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const float* __restrict__ w,
                                                        const float* __restrict__ b, float* __restrict__ recon,
-                                                       long npix, int hw) {
+                                                       long npix, int hw, int hwshift) {
     const int sub = threadIdx.x & 7, c0 = sub * 8;
     float sc[8], sh[8], wv[CO][8];
     load8f(scale + c0, sc);
@@ -430,8 +430,10 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const bf16_t* __restrict_
             float l = 0.f;
 #pragma unroll
             for (int o = 0; o < CO; ++o) if (sub == o) l = acc[o] + b[o];
-            const long img = pix / hw, p = pix % hw;
-            recon[(img * CO + sub) * hw + p] = 1.f / (1.f + expf(-l));
+            // npix < 2^31: 32-bit index math, shifts when the image is a power of two
+            const unsigned up = (unsigned)pix;
+            const unsigned img = hwshift >= 0 ? up >> hwshift : up / (unsigned)hw, p = up - img * (unsigned)hw;
+            recon[((long)img * CO + sub) * hw + p] = 1.f / (1.f + expf(-l));
         }
     }
 }
@@ -445,7 +447,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ rstd, const float* __restrict__ w,
                                                        const float* __restrict__ sums, float inv_count,
                                                        float* __restrict__ partial, bf16_t* __restrict__ dy, long npix,
-                                                       int hw) {
+                                                       int hw, int hwshift) {
     constexpr int ROWS = 3 + CO;
     __shared__ float red[ROWS][32][64 + 1];
     const int sub = threadIdx.x & 7, c0 = sub * 8, pl = threadIdx.x >> 3;
@@ -472,18 +474,37 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
 #pragma unroll
     for (int o = 0; o < CO; ++o) a_b[o] = 0.f;
 
+    // two pixels per trip: both pixels' loads are issued before either is used (the loop is one dependent chain
+    // per lane otherwise, and a launch this wide lives on loads in flight)
     const long stride = (long)gridDim.x * 32;
-    for (long pix = (long)blockIdx.x * 32 + pl; pix < npix; pix += stride) {
-        const long img = pix / hw, p = pix % hw;
-        float dl[CO];
+    for (long pix0 = (long)blockIdx.x * 32 + pl; pix0 < npix; pix0 += 2 * stride) {
+        float vv[2][8], dd[2][CO];
+        bool okk[2];
 #pragma unroll
-        for (int o = 0; o < CO; ++o) {
-            const long e = (img * CO + o) * hw + p;
-            const float r = recon[e];
-            dl[o] = drecon[e] * r * (1.f - r);
+        for (int u = 0; u < 2; ++u) {
+            const long pix = pix0 + u * stride;
+            okk[u] = pix < npix;
+            if (okk[u]) {
+                const unsigned up = (unsigned)pix;      // npix < 2^31
+                const unsigned img = hwshift >= 0 ? up >> hwshift : up / (unsigned)hw, p = up - img * (unsigned)hw;
+#pragma unroll
+                for (int o = 0; o < CO; ++o) {
+                    const long e = ((long)img * CO + o) * hw + p;
+                    const float r = recon[e];
+                    dd[u][o] = drecon[e] * r * (1.f - r);
+                }
+                load8(y + pix * 64 + c0, vv[u]);
+            }
         }
-        float v[8], o8[8];
-        load8(y + pix * 64 + c0, v);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+        if (!okk[u]) continue;
+        const long pix = pix0 + u * stride;
+        float v[8], o8[8], dl[CO];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = vv[u][i];
+#pragma unroll
+        for (int o = 0; o < CO; ++o) dl[o] = dd[u][o];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const float a = v[i] * sc[i] + sh[i];
@@ -508,6 +529,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
             for (int o = 0; o < CO; ++o) a_b[o] += dl[o];
         }
         if (PASS == 1) store8(dy + pix * 64 + c0, o8);
+        }
     }
     if (PASS == 0) {
 #pragma unroll
@@ -715,13 +737,13 @@ extern "C" int vae_bn_act_bwd_route(const void* gin, const void* y, const float*
 extern "C" int vae_head_fwd(const void* y, const float* scale, const float* shift, const float* w, const float* b,
                             float* recon, int n_img, int H, int W, int Cout, void* stream) {
     VAE_CHECK(y && scale && shift && w && b && recon, "vae_head_fwd: null pointer");
-    VAE_CHECK(n_img > 0 && H > 0 && W > 0, "vae_head_fwd: bad geometry");
+    VAE_CHECK(n_img > 0 && H > 0 && W > 0 && (long)n_img * H * W < (1L << 31), "vae_head_fwd: bad geometry");
     VAE_CHECK(Cout >= 1 && Cout <= 4, "vae_head_fwd: out_channels=%d not supported (1..4)", Cout);
     const long npix = (long)n_img * H * W;
     const int grid = elem_grid(npix * 8);
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof("head_fwd_kernel", 2.0 * npix * 64 * Cout, npix * (128.0 + 4.0 * Cout), s);
-#define GO(CO) hipLaunchKernelGGL(head_fwd_kernel<CO>, dim3(grid), dim3(256), 0, s, (const bf16_t*)y, scale, shift, w, b, recon, npix, H * W)
+#define GO(CO) hipLaunchKernelGGL(head_fwd_kernel<CO>, dim3(grid), dim3(256), 0, s, (const bf16_t*)y, scale, shift, w, b, recon, npix, H * W, pow2_shift(H * W))
     switch (Cout) { case 1: GO(1); break; case 2: GO(2); break; case 3: GO(3); break; default: GO(4); }
 #undef GO
     VAE_LAUNCH_CHECK("head_fwd_kernel");
@@ -731,7 +753,7 @@ extern "C" int vae_head_fwd(const void* y, const float* scale, const float* shif
 extern "C" int vae_head_bwd_blocks(int n_img, int H, int W) {
     long b = ((long)n_img * H * W + 31) / 32;
     if (b < 1) b = 1;
-    if (b > 512) b = 512;
+    if (b > 1024) b = 1024;
     return (int)b;
 }
 
@@ -739,7 +761,7 @@ extern "C" int vae_head_bwd(const float* drecon, const float* recon, const void*
                             const float* shift, const float* mean, const float* rstd, const float* w, float* partial,
                             float* sums, float* sums_head, void* dy, int n_img, int H, int W, int Cout, void* stream) {
     VAE_CHECK(drecon && recon && y && scale && shift && mean && rstd && w && partial && sums && sums_head && dy, "vae_head_bwd: null pointer");
-    VAE_CHECK(n_img > 0 && H > 0 && W > 0, "vae_head_bwd: bad geometry");
+    VAE_CHECK(n_img > 0 && H > 0 && W > 0 && (long)n_img * H * W < (1L << 31), "vae_head_bwd: bad geometry");
     VAE_CHECK(Cout >= 1 && Cout <= 4, "vae_head_bwd: out_channels=%d not supported (1..4)", Cout);
     const long npix = (long)n_img * H * W;
     const int nb = vae_head_bwd_blocks(n_img, H, W);
@@ -748,7 +770,7 @@ extern "C" int vae_head_bwd(const float* drecon, const float* recon, const void*
     hipStream_t s = (hipStream_t)stream;
     const bf16_t* yy = (const bf16_t*)y;
     ProfScope prof("head_bwd(reduce+apply)", 0.0, npix * (2 * 128.0 + 2 * 8.0 * Cout + 128.0), s);
-#define GO(CO, PASS, NB) hipLaunchKernelGGL((head_bwd_kernel<CO, PASS>), dim3(NB), dim3(256), 0, s, drecon, recon, yy, scale, shift, mean, rstd, w, sums, inv_count, partial, (bf16_t*)dy, npix, H * W)
+#define GO(CO, PASS, NB) hipLaunchKernelGGL((head_bwd_kernel<CO, PASS>), dim3(NB), dim3(256), 0, s, drecon, recon, yy, scale, shift, mean, rstd, w, sums, inv_count, partial, (bf16_t*)dy, npix, H * W, pow2_shift(H * W))
     switch (Cout) { case 1: GO(1, 0, nb); break; case 2: GO(2, 0, nb); break; case 3: GO(3, 0, nb); break; default: GO(4, 0, nb); }
     VAE_LAUNCH_CHECK("head_bwd_kernel<0>");
     // [d gamma | d beta] -> sums (also the coefficients of pass 1); [dW | db] -> sums_head
