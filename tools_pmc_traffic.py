@@ -26,10 +26,10 @@ def bench_name(rocprof_name: str):
     m = re.search(r"gemm_tn_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), \d+>", n)
     if m:
         return "gemm_tn_kernel<" + ",".join(m.groups()) + ">"
-    m = re.search(r"gemm_nt_kernel<(\d+), (\d+), (\d+)>", n)
+    m = re.search(r"gemm_nt_kernel<(\d+), (\d+), (\d+), \d+>", n)
     if m:
         return "gemm_nt_kernel<" + ",".join(m.groups()) + ">"
-    m = re.search(r"bn_act_bwd_kernel<(true|false), \d>", n)
+    m = re.search(r"bn_act_bwd_kernel<(true|false), \d", n)
     if m:
         return "bn_act_bwd(reduce+apply)" + ("<pool>" if m.group(1) == "true" else "")
     m = re.search(r"bn_act_fwd_kernel<(true|false)>", n)

@@ -630,7 +630,7 @@ extern "C" int vae_bn_finalize(float* stat_sum, float* stat_sq, int rows, int C,
     VAE_CHECK(use_running ? (running_mean && running_var) : (stat_sum && stat_sq && rows > 0 && count > 0),
               "vae_bn_finalize: missing statistics input");
     VAE_CHECK(C > 0 && fold > 0, "vae_bn_finalize: bad C=%d fold=%d", C, fold);
-    if (!use_running && rows > 1024) {
+    if (!use_running && rows > 512) {
         // many partial rows: fold them to 32 scratch rows with the whole chip first
         const int ncols = fold * C;
         hipLaunchKernelGGL(stats_stage1_kernel, dim3((ncols + 63) / 64, VAE_STAT_SCRATCH_ROWS), dim3(256), 0,
