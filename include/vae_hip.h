@@ -243,6 +243,13 @@ int vae_tanh_bwd(const void* dx, const void* h, void* dpre, float* colpartial, i
                  void* stream);
 /* inputs.to(device) (train.py:325): NCHW f32 image batch -> NHWC bf16 padded to 8 channels */
 int vae_nchw_to_nhwc8(const float* x, void* out, int n_img, int C, int H, int W, void* stream);
+/* Batch feed from a dataset resident in HBM: out[b][c][h][w] = data[index[b]][h][w][c] / 255 (fp32, the
+ * value torchvision's ToTensor gives).  Replaces the host-side batch assembly of the reference's DataLoader
+ * (vae/training/train.py:158-179: random_split + DataLoader(shuffle); :266-274: CIFAR10 / ToTensor).
+ * data: n_data images, uint8, HWC; index: batch int64 image indices (device memory; negative values count
+ * from the end; null = images 0..batch-1); an index outside the dataset yields a zero image. */
+int vae_feed_u8(const void* data_u8_nhwc, long n_data, const long* index, float* out_nchw, int batch, int C,
+                int H, int W, void* stream);
 /* dst[base + i0*s0+i1*s1+i2*s2+i3*s3] = src[e] (fp32 permuting copy); dst_bf16[i] = bf16(src[i]) */
 int vae_permute_f32(const float* src, float* dst, const long* dims4, const long* strides4, long base,
                     void* stream);

@@ -1,0 +1,104 @@
+"""GPU tests of the device-side batch feed (through the C ABI) and of the checkpoint / sampling helpers around the model.
+The feed must give exactly what torchvision's ToTensor gives on the host: HWC uint8 -> CHW fp32, value / 255."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _ref(images_u8, idx):
+    x = torch.from_numpy(images_u8)[idx]                       # [B, H, W, C]
+    return x.permute(0, 3, 1, 2).contiguous().float().div(255)
+
+
+@pytest.mark.parametrize("n,h,w,c,batch", [(64, 32, 32, 3, 16), (10, 5, 7, 1, 10), (33, 8, 8, 4, 5), (9, 64, 64, 3, 9)])
+def test_feed_matches_totensor_bit_for_bit(n, h, w, c, batch):
+    from vae_amd import _lib as L
+    rng = np.random.default_rng(n + h)
+    images = rng.integers(0, 256, size=(n, h, w, c), dtype=np.uint8)
+    images[0] = 0
+    images[-1] = 255
+    idx = torch.from_numpy(rng.integers(-n, n, size=batch)).long()
+    idx[0], idx[-1] = 0, -1
+    d = torch.from_numpy(images).to(DEV)
+    out = torch.full((batch, c, h, w), float("nan"), device=DEV)
+    L.call("vae_feed_u8", d.data_ptr(), n, idx.to(DEV).data_ptr(), out.data_ptr(), batch, c, h, w, L.current_stream())
+    assert torch.equal(out.cpu(), _ref(images, idx))
+    # no index: the first `batch` images
+    out.fill_(float("nan"))
+    L.call("vae_feed_u8", d.data_ptr(), n, None, out.data_ptr(), batch, c, h, w, L.current_stream())
+    assert torch.equal(out.cpu(), _ref(images, torch.arange(batch)))
+    # an index outside the dataset gives a zero image, the rest is untouched by it
+    bad = idx.clone()
+    bad[1 % batch] = n + 3
+    L.call("vae_feed_u8", d.data_ptr(), n, bad.to(DEV).data_ptr(), out.data_ptr(), batch, c, h, w, L.current_stream())
+    ref = _ref(images, idx)
+    ref[1 % batch] = 0
+    assert torch.equal(out.cpu(), ref)
+
+
+def test_feed_rejects_bad_arguments():
+    from vae_amd import _lib as L
+    d = torch.zeros(4, 8, 8, 3, dtype=torch.uint8, device=DEV)
+    out = torch.empty(8, 3, 8, 8, device=DEV)
+    with pytest.raises(RuntimeError, match="channels=2"):
+        L.call("vae_feed_u8", d.data_ptr(), 4, None, out.data_ptr(), 4, 2, 8, 8, L.current_stream())
+    with pytest.raises(RuntimeError, match="exceeds"):
+        L.call("vae_feed_u8", d.data_ptr(), 4, None, out.data_ptr(), 8, 3, 8, 8, L.current_stream())
+    with pytest.raises(RuntimeError, match="null pointer"):
+        L.call("vae_feed_u8", None, 4, None, out.data_ptr(), 4, 3, 8, 8, L.current_stream())
+
+
+def test_device_feed_epochs():
+    from vae_amd import data
+    rng = np.random.default_rng(3)
+    images = rng.integers(0, 256, size=(103, 16, 16, 3), dtype=np.uint8)
+    tr, va = data.split_indices(103, 0.9, torch.Generator().manual_seed(1337))
+    feed = data.DeviceFeed(images, 32, indices=va, shuffle=False)
+    got = torch.cat([b.cpu() for b in feed])
+    assert torch.equal(got, _ref(images, va))                          # validation order is the split's order
+    g = torch.Generator().manual_seed(5)
+    feed = data.DeviceFeed(images, 32, indices=tr, shuffle=True, generator=g)
+    assert len(feed) == 3
+    e1 = [b.cpu() for b in feed]
+    e2 = [b.cpu() for b in feed]
+    assert [b.shape[0] for b in e1] == [32, 32, 28]                    # the short last batch is kept
+    a, b = torch.cat(e1), torch.cat(e2)
+    assert not torch.equal(a, b)                                       # a new permutation per epoch
+    # each epoch is a permutation of the training subset
+    key = lambda t: sorted(t.flatten(1).sum(1).tolist())
+    assert key(a) == key(_ref(images, tr)) == key(b)
+    out = torch.empty(4, 3, 16, 16, device=DEV)
+    assert feed.batch(torch.tensor([0, 1, 2, -1]), out=out) is out
+
+
+def test_checkpoint_and_sampling_through_the_model(tmp_path):
+    from vae_amd import data
+    from vae_amd.vae import VAEConv
+    torch.manual_seed(11)
+    m = VAEConv(3, 3, 64, 0.1, 16).to(DEV)
+    x = torch.rand(8, 3, 16, 16, device=DEV)
+    m.train()
+    m(x)                                                               # moves the BatchNorm running statistics
+    path = str(tmp_path / "best-model.pth")
+    data.save_checkpoint(m, path)
+    raw = torch.load(path, map_location="cpu", weights_only=True)
+    assert len(raw) == 85 and "conv1.net.0.weight" in raw and "bn1.num_batches_tracked" in raw   # the reference's 85 entries
+    m2 = VAEConv(3, 3, 64, 0.1, 16).to(DEV)
+    res = data.load_checkpoint(m2, path)
+    assert not res.missing_keys and not res.unexpected_keys
+    m.eval(), m2.eval()
+    with torch.no_grad():
+        (mu1, lv1), (mu2, lv2) = m.encode(x), m2.encode(x)             # running statistics came along
+    assert torch.equal(mu1, mu2) and torch.equal(lv1, lv2)
+    m.train(), m2.train()
+    r1 = data.reconstruct(m, x)                                        # stochastic: eps is drawn in eval mode too (vae.py:108-111)
+    assert r1.shape == x.shape and float(r1.min()) > 0 and float(r1.max()) < 1
+    assert m.training and m2.training                                  # the helpers restore the mode
+    s1 = data.sample(m, 6, torch.Generator(device=DEV).manual_seed(3))
+    s2 = data.sample(m2, 6, torch.Generator(device=DEV).manual_seed(3))
+    assert s1.shape == (6, 3, 16, 16) and torch.equal(s1, s2)
+    assert float(s1.min()) > 0 and float(s1.max()) < 1
+    data.save_image_grid(s1, str(tmp_path / "samples.ppm"), nrow=3)

@@ -67,6 +67,7 @@ SIGNATURES = {
     "vae_tanh_bwd_rows": (c_int, [c_int]),
     "vae_tanh_bwd": (None, [P, P, P, P, c_int, c_int, P]),
     "vae_nchw_to_nhwc8": (None, [P, P, c_int, c_int, c_int, c_int, P]),
+    "vae_feed_u8": (None, [P, c_long, P, P, c_int, c_int, c_int, c_int, P]),
     "vae_adamw_grid": (c_int, [c_long]),
     "vae_adamw_clip_step": (None, [P, P, P, P, c_long, P, c_float, c_float, c_double, c_double, c_double,
                                    c_double, c_double, c_int, P, P]),

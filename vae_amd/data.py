@@ -1,0 +1,165 @@
+"""The steps either side of the training path: batches and checkpoints.
+
+* ``split_indices`` / ``DeviceFeed`` stand in for the reference's ``random_split`` + ``DataLoader``
+  (vae/training/train.py:156-179) over a ``ToTensor`` dataset (train.py:258-274): the whole dataset
+  sits in HBM as uint8 HWC images (CIFAR-10: 150 MB, CelebA 64x64: 2.5 GB -- a fraction of one GPU's
+  memory), a batch is one gather + uint8 -> fp32/255 kernel on the training stream, and no host
+  worker or PCIe copy runs per step.
+* ``save_checkpoint`` / ``load_checkpoint`` write and read the reference's ``best-model.pth``: a
+  plain ``state_dict`` (train.py:360-367, 187-207), loaded with ``weights_only=True``.
+* ``sample`` / ``reconstruct`` / ``save_image_grid`` cover train.py:58-112 (show_reconstructions,
+  show_samples) without matplotlib: they return tensors and write a PPM/PNG grid.
+
+There is no CPU path here either: ``DeviceFeed`` calls the HIP library and fails if it is absent.
+"""
+from __future__ import annotations
+
+import os
+from typing import Iterator, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def split_indices(n: int, p_train_len: float, generator: Optional[torch.Generator] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """``random_split(dataset, [train_len, n - train_len])`` of train.py:157-159 as index tensors:
+    ``train_len = int(n * p_train_len)``, one ``randperm(n)`` (torch's own ``random_split`` draws
+    exactly that from the same generator), first ``train_len`` entries train, the rest validate."""
+    if n <= 0:
+        raise ValueError(f"empty dataset (n={n})")
+    if not 0.0 <= p_train_len <= 1.0:
+        raise ValueError(f"p_train_len={p_train_len} out of [0, 1]")
+    train_len = int(n * p_train_len)
+    perm = torch.randperm(n, generator=generator)
+    return perm[:train_len].clone(), perm[train_len:].clone()
+
+
+class DeviceFeed:
+    """A uint8 image dataset resident on the GPU and an iterator of fp32 NCHW batches in [0, 1].
+
+    ``images``: uint8 array / tensor ``[N, H, W, C]`` (or ``[N, H, W]`` for one channel).
+    ``indices``: the subset to draw from (``split_indices``), default all.
+    ``shuffle``: a fresh permutation of ``indices`` per epoch (DataLoader(shuffle=True), train.py:163),
+    drawn on the host from ``generator``.  The last, short batch of an epoch is kept
+    (DataLoader's ``drop_last=False``).
+    """
+
+    def __init__(self, images, batch_size: int, indices: Optional[torch.Tensor] = None, shuffle: bool = False,
+                 device="cuda", generator: Optional[torch.Generator] = None):
+        t = torch.as_tensor(np.asarray(images) if not torch.is_tensor(images) else images)
+        if t.dtype != torch.uint8:
+            raise TypeError(f"DeviceFeed wants uint8 images, got {t.dtype}")
+        if t.dim() == 3:
+            t = t.unsqueeze(-1)
+        if t.dim() != 4 or t.size(-1) not in (1, 3, 4):
+            raise ValueError(f"DeviceFeed wants [N, H, W, C] with C in (1, 3, 4), got {tuple(t.shape)}")
+        if batch_size <= 0:
+            raise ValueError(f"batch_size={batch_size}")
+        self.n, self.h, self.w, self.c = (int(v) for v in t.shape)
+        self.batch_size = int(batch_size)
+        self.shuffle = bool(shuffle)
+        self.generator = generator
+        idx = torch.arange(self.n) if indices is None else torch.as_tensor(indices, dtype=torch.int64).clone()
+        if idx.numel() == 0:
+            raise ValueError("DeviceFeed: empty index set")
+        if int(idx.min()) < -self.n or int(idx.max()) >= self.n:
+            raise IndexError(f"DeviceFeed: index out of range for {self.n} images")
+        self.indices = idx
+        self.device = torch.device(device)
+        _lib.load()                                   # fails loudly when the HIP library is missing
+        self.data = t.contiguous().to(self.device)
+
+    def __len__(self) -> int:
+        return (self.indices.numel() + self.batch_size - 1) // self.batch_size
+
+    def batch(self, index: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """fp32 ``[len(index), C, H, W]`` = the indexed images / 255, on the current stream.  ``index`` may live
+        on the host (copied) or the device."""
+        idx = index.to(device=self.device, dtype=torch.int64).contiguous()
+        b = int(idx.numel())
+        if out is None:
+            out = torch.empty(b, self.c, self.h, self.w, device=self.device, dtype=torch.float32)
+        elif tuple(out.shape) != (b, self.c, self.h, self.w) or out.dtype != torch.float32 or not out.is_contiguous():
+            raise ValueError("DeviceFeed.batch: out must be a contiguous fp32 [B, C, H, W] tensor")
+        _lib.call("vae_feed_u8", self.data.data_ptr(), self.n, idx.data_ptr(), out.data_ptr(), b, self.c, self.h, self.w,
+                  _lib.current_stream())
+        return out
+
+    def __iter__(self) -> Iterator[torch.Tensor]:
+        order = self.indices
+        if self.shuffle:
+            order = order[torch.randperm(order.numel(), generator=self.generator)]
+        order = order.to(self.device)                 # one small copy per epoch
+        for s in range(0, order.numel(), self.batch_size):
+            yield self.batch(order[s:s + self.batch_size])
+
+
+# ---------------------------------------------------------------------------------------- checkpoints
+def save_checkpoint(model: torch.nn.Module, path: str) -> None:
+    """``torch.save(model.state_dict(), path)`` (train.py:365): tensors on the CPU, reference names and shapes."""
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    torch.save(sd, path)
+
+
+def load_checkpoint(model: torch.nn.Module, path: str, strict: bool = True):
+    """``model.load_state_dict(torch.load(path, map_location="cpu"))`` (train.py:187,207), restricted to
+    tensor-only files (``weights_only=True``: nothing in the file is executed)."""
+    sd = torch.load(path, map_location="cpu", weights_only=True)
+    if not isinstance(sd, dict):
+        raise TypeError(f"{path} does not hold a state_dict")
+    return model.load_state_dict(sd, strict=strict)
+
+
+# ---------------------------------------------------------------------------------------- sampling
+@torch.no_grad()
+def sample(model, n: int, generator: Optional[torch.Generator] = None) -> torch.Tensor:
+    """``model.decode(randn(n, latent))`` in eval mode (show_samples, train.py:86-112): ``[n, C, S, S]`` in (0, 1)."""
+    was_training = model.training
+    model.eval()
+    dev = next(model.parameters()).device
+    z = torch.randn(n, model.fc_mu.weight.shape[0], device=dev, generator=generator)     # [latent, features]
+    out = model.decode(z)
+    model.train(was_training)
+    return out
+
+
+@torch.no_grad()
+def reconstruct(model, inputs: torch.Tensor) -> torch.Tensor:
+    """eval-mode ``model(inputs)[0]`` (show_reconstructions, train.py:58-83)."""
+    was_training = model.training
+    model.eval()
+    recon = model(inputs)[0]
+    model.train(was_training)
+    return recon
+
+
+def save_image_grid(images: torch.Tensor, path: str, nrow: int = 8, padding: int = 2) -> None:
+    """Tile ``[N, C, H, W]`` images in [0, 1] into one picture (the layout of torchvision's make_grid: ``nrow`` images
+    per row, ``padding`` black pixels between them) and write it: ``.ppm`` / ``.pgm`` natively, anything else via PIL."""
+    x = images.detach().float().clamp(0, 1).cpu()
+    if x.dim() != 4:
+        raise ValueError("save_image_grid wants [N, C, H, W]")
+    n, c, h, w = x.shape
+    if c == 1:
+        x = x.expand(n, 3, h, w)
+    elif c != 3:
+        raise ValueError(f"save_image_grid: {c} channels")
+    cols = min(nrow, n)
+    rows = (n + cols - 1) // cols
+    grid = torch.zeros(3, rows * (h + padding) + padding, cols * (w + padding) + padding)
+    for i in range(n):
+        r, q = divmod(i, cols)
+        y0, x0 = padding + r * (h + padding), padding + q * (w + padding)
+        grid[:, y0:y0 + h, x0:x0 + w] = x[i]
+    arr = (grid * 255.0 + 0.5).clamp(0, 255).to(torch.uint8).permute(1, 2, 0).contiguous().numpy()
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    if path.lower().endswith((".ppm", ".pgm")):
+        with open(path, "wb") as f:
+            f.write(f"P6\n{arr.shape[1]} {arr.shape[0]}\n255\n".encode())
+            f.write(arr.tobytes())
+    else:
+        from PIL import Image
+        Image.fromarray(arr).save(path)
