@@ -44,6 +44,15 @@ def test_shipped_benchmark_configs(env, latent, size, batch, klw):
     assert train.recon_kind_from_config(cfg) in train.RECON_KINDS.values()
 
 
+def test_linear_anneal_kl():
+    cfg = train.Config(n_epochs=10, kl_clip=0.5, kl_start=0.0, kl_end=4.0)
+    assert train.linear_anneal_kl(cfg, 0) == 0.0
+    assert train.linear_anneal_kl(cfg, 2) == pytest.approx(0.8)
+    assert train.linear_anneal_kl(cfg, 5) == 2.0 == train.linear_anneal_kl(cfg, 9)     # clipped at kl_clip
+    cfg2 = train.Config(n_epochs=4, kl_clip=1.0, kl_start=1.0, kl_end=0.5)
+    assert train.linear_anneal_kl(cfg2, 4) == 0.5 and train.linear_anneal_kl(cfg2, 2) == 0.75
+
+
 def test_loss_kind_selection():
     assert train._kind_of(F.l1_loss) == 0 and train._kind_of(F.mse_loss) == 1
     assert train._kind_of(F.binary_cross_entropy) == 2 and train._kind_of(F.binary_cross_entropy_with_logits) == 3

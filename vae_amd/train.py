@@ -127,6 +127,15 @@ def l1_kl_percep_loss(recons, inputs, mu, logvar, config, LPIPS_FN=None):
     return vae_loss(recons, inputs, mu, logvar, F.l1_loss, LPIPS_FN, config)
 
 
+def linear_anneal_kl(config, epoch) -> float:
+    """KL weight schedule of the draft training script (vae/practice/vae_conv.py:154-157):
+    ``kl_start + (kl_end - kl_start) * min(epoch / n_epochs, kl_clip)``.  The live loop uses the constant
+    ``config.kl_weight`` (train.py:50); to anneal, assign the result to ``config.kl_weight`` at the top of each
+    epoch -- the loss kernels take the weight as a per-call scalar."""
+    progress = min(epoch / config.n_epochs, config.kl_clip)
+    return config.kl_start + (config.kl_end - config.kl_start) * progress
+
+
 def recon_kind_from_config(config) -> int:
     return RECON_KINDS[getattr(config, "recon_loss", "l1") if "recon_loss" in config else "l1"]
 
