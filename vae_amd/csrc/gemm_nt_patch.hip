@@ -170,7 +170,10 @@ __global__ __launch_bounds__(512, 1) void conv3_wgrad_patch_kernel(const PatchP 
         const int kt = kt_beg + 2 * it;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (kt + 2 < kt_end) stage((it + 1) & 1, kt + 2);
+        // The copies for the next round cost the issuing wave ~150 cycles apiece (9 per wave).  Each SIMD holds one wave
+        // of either group: group 0 issues its copies now, group 1 after its first 36 MFMAs, so that one group's matrix
+        // instructions run under the other's copy issue instead of all eight waves issuing, then all computing.
+        if (grp == 0 && kt + 2 < kt_end) stage((it + 1) & 1, kt + 2);
         if (kt >= kt_end) continue;                       // odd tile count: group 1 idles in the last round
         const unsigned char* sbase = smem + (2 * (it & 1) + grp) * STAGE;
 #pragma unroll
@@ -194,38 +197,54 @@ __global__ __launch_bounds__(512, 1) void conv3_wgrad_patch_kernel(const PatchP 
                 for (int j = 0; j < 4; ++j)
                     acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[t & 1], pb[j], acc[t][j], 0, 0, 0);
             }
+            if (kk == 0 && grp == 1 && kt + 2 < kt_end) stage((it + 1) & 1, kt + 2);
         }
     }
 
-    // fold group 1 into group 0 through LDS (the staging buffers are dead)
+    // The two groups hold partial sums of the same tile.  They swap halves through LDS (the staging buffers are
+    // dead): group 0 ends up with the complete taps 0-4, group 1 with taps 5-8, and each stores its share of the
+    // slab -- eight waves fold and store instead of four.  (a + b == b + a bit for bit: the order is immaterial.)
     __syncthreads();
     float4* fold = (float4*)smem + (wave * 64 + lane);
-    if (grp == 1) {
+    if (grp == 0) {
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
+        for (int t = 5; t < 9; ++t)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                fold[(t * 4 + j) * 256] = make_float4(acc[t][j][0], acc[t][j][1], acc[t][j][2], acc[t][j][3]);
+                fold[((t - 5) * 4 + j) * 256] = make_float4(acc[t][j][0], acc[t][j][1], acc[t][j][2], acc[t][j][3]);
+    } else {
+#pragma unroll
+        for (int t = 0; t < 5; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                fold[(16 + t * 4 + j) * 256] = make_float4(acc[t][j][0], acc[t][j][1], acc[t][j][2], acc[t][j][3]);
     }
     __syncthreads();
-    if (grp == 1) return;
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float4 o = fold[(t * 4 + j) * 256];
-            acc[t][j][0] += o.x; acc[t][j][1] += o.y; acc[t][j][2] += o.z; acc[t][j][3] += o.w;
-        }
-
     // acc[t][j][r]: ci = n0 + wave*16 + (lane>>4)*4 + r ; co = m0 + j*16 + (lane&15)
     float* out = p.slab + (long)split * p.slab_stride;
     const int ci = n0 + wave * 16 + (lane >> 4) * 4;
+    if (grp == 0) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int co = m0 + j * 16 + (lane & 15);
+        for (int j = 0; j < 4; ++j) {
+            const int co = m0 + j * 16 + (lane & 15);
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
-            *(float4*)(out + ((long)co * 9 + t) * p.Ci + ci) = make_float4(acc[t][j][0], acc[t][j][1], acc[t][j][2], acc[t][j][3]);
+            for (int t = 0; t < 5; ++t) {
+                const float4 o = fold[(16 + t * 4 + j) * 256];
+                *(float4*)(out + ((long)co * 9 + t) * p.Ci + ci) =
+                    make_float4(acc[t][j][0] + o.x, acc[t][j][1] + o.y, acc[t][j][2] + o.z, acc[t][j][3] + o.w);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int co = m0 + j * 16 + (lane & 15);
+#pragma unroll
+            for (int t = 5; t < 9; ++t) {
+                const float4 o = fold[((t - 5) * 4 + j) * 256];
+                *(float4*)(out + ((long)co * 9 + t) * p.Ci + ci) =
+                    make_float4(acc[t][j][0] + o.x, acc[t][j][1] + o.y, acc[t][j][2] + o.z, acc[t][j][3] + o.w);
+            }
+        }
     }
 }
 
