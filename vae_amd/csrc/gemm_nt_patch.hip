@@ -97,6 +97,14 @@ __global__ __launch_bounds__(512, 1) void conv3_wgrad_patch_kernel(const PatchP 
     const int p_row0 = wave * 8 + (lane >> 3);
     const int p_ch0 = (lane & 7) ^ swz128(p_row0);
 
+    // copies are buffer_load ... lds: a 32-bit byte offset per lane against a descriptor in SGPRs; an offset past the
+    // buffer delivers zeros -- halo pixels, rows outside the image and the K tail cost a select, not a branch and a
+    // 64-bit pointer
+    constexpr unsigned OOB = 0xFFFFFFFFu;
+    const __amdgpu_buffer_rsrc_t p_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)p.P, 0, (int)((unsigned)p.Ktot * (unsigned)p.Co * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t q_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)p.Q, 0, (int)((unsigned)p.Ktot * (unsigned)p.Ci * 2u), 0x00020000);
     auto stage = [&](int buf, int kt) {
         unsigned char* pbase = smem + (2 * buf + grp) * STAGE;
         unsigned char* qbase = pbase + P_BYTES;
@@ -105,26 +113,24 @@ __global__ __launch_bounds__(512, 1) void conv3_wgrad_patch_kernel(const PatchP 
             int ra = p_row0, ca = p_ch0;
             asm volatile("" : "+v"(ra), "+v"(ca));      // keep the address math inside the loop (registers are scarce here)
             const int ka = k0 + ra, kb = ka + 32;       // rows 32 apart agree in both swizzle bits
-            const unsigned char* pcol = (const unsigned char*)(p.P + m0);
             const unsigned prow = (unsigned)p.Co * 2;
-            const unsigned char* sa = ka < p.Ktot ? pcol + ((unsigned)ka * prow + ca * 16) : (const unsigned char*)zero;
-            const unsigned char* sb = kb < p.Ktot ? pcol + ((unsigned)kb * prow + ca * 16) : (const unsigned char*)zero;
-            __builtin_amdgcn_global_load_lds((gptr_t)sa, (lptr_t)(pbase + wave * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)sb, (lptr_t)(pbase + (wave + 4) * 1024), 16, 0, 0);
+            const unsigned oa = ka < p.Ktot ? (unsigned)ka * prow + (unsigned)(m0 * 2 + ca * 16) : OOB;
+            const unsigned ob = kb < p.Ktot ? (unsigned)kb * prow + (unsigned)(m0 * 2 + ca * 16) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(p_rsrc, (lptr_t)(pbase + wave * 1024), 16, (int)oa, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(p_rsrc, (lptr_t)(pbase + (wave + 4) * 1024), 16, (int)ob, 0, 0, 0);
         }
-        const unsigned char* qcol = (const unsigned char*)(p.Q + n0);
         const unsigned rowb = (unsigned)p.Ci * 2;
         const int h0 = p.G == 1 ? ((k0 >> p.wshift) & (p.H - 1)) : 0;
 #pragma unroll
         for (int i = 0; i < PATCH_INSTR_PER_WAVE; ++i) {
             if (wave + 4 * i < ninstr) {     // wave-uniform
-                const unsigned char* src = (const unsigned char*)zero;
                 int st = q_st[i];
                 asm volatile("" : "+v"(st));
                 const int k = k0 + (st & 255) - 128, r = ((st >> 8) & 255) - 1;
+                unsigned off = OOB;
                 if ((st >> 24) && (unsigned)(h0 + r) < (unsigned)p.H && (unsigned)k < (unsigned)p.Ktot)
-                    src = qcol + ((unsigned)k * rowb + ((st >> 12) & 0x70));
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(qbase + (wave + 4 * i) * 1024), 16, 0, 0);
+                    off = (unsigned)k * rowb + (unsigned)(n0 * 2 + ((st >> 12) & 0x70));
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(q_rsrc, (lptr_t)(qbase + (wave + 4 * i) * 1024), 16, (int)off, 0, 0, 0);
             }
         }
     };
