@@ -164,6 +164,19 @@ int vae_reduce_slabs(const float* slab, int nsplit, long slab_stride, float* out
 int vae_reduce_slabs_scatter(const float* slab, int nsplit, long slab_stride, long slab_base,
                              float* out, const long* dims4, const long* strides4,
                              const long* limits4, long base, int accumulate, void* stream);
+/* Several vae_reduce_slabs_scatter folds in one launch (all the weight gradients of a backward stage:
+ * the folds are a few microseconds each and only the optimizer waits for them). */
+#define VAE_MAX_REDUCE_JOBS 12
+typedef struct vae_reduce_job {
+    const float* slab;
+    int nsplit;
+    long slab_stride, slab_base;
+    float* out;
+    long dims[4], strides[4], limits[4];   /* as in vae_reduce_slabs_scatter; limits = dims when nothing is padding */
+    long base;
+    int accumulate;
+} vae_reduce_job;
+int vae_multi_reduce_slabs_scatter(const vae_reduce_job* jobs, int njobs, void* stream);
 /* Many pack / permute jobs in one launch (all weights of the model after an optimizer step). */
 #define VAE_MAX_PACK_JOBS 40
 typedef struct vae_pack_job {

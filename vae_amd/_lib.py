@@ -64,6 +64,7 @@ SIGNATURES = {
     "vae_head_bwd": (None, [P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "vae_reduce_slabs_scatter": (None, [P, c_int, c_long, c_long, P, P, P, P, c_long, c_int, P]),
     "vae_multi_pack": (None, [P, c_int, P]),
+    "vae_multi_reduce_slabs_scatter": (None, [P, c_int, P]),
     "vae_tanh_bwd_rows": (c_int, [c_int]),
     "vae_tanh_bwd": (None, [P, P, P, P, c_int, c_int, P]),
     "vae_nchw_to_nhwc8": (None, [P, P, c_int, c_int, c_int, c_int, P]),

@@ -244,11 +244,10 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
 struct Limits {
     int l0, l1, l2, l3;
 };
-__global__ __launch_bounds__(256) void reduce_slabs_scatter_kernel(const float* __restrict__ slab, int nsplit,
-                                                                   long slab_stride, float* __restrict__ out, long n,
-                                                                   IndexMap mp, Limits lim, int accumulate) {
+__device__ __forceinline__ void reduce_slabs_scatter_body(const float* __restrict__ slab, int nsplit, long slab_stride,
+                                                          float* __restrict__ out, long n, const IndexMap& mp,
+                                                          const Limits& lim, int accumulate, float4 (*red)[64]) {
     // 64 lanes x 16 bytes of consecutive slab elements, 4 split groups per workgroup (n % 4 == 0)
-    __shared__ float4 red[4][64];
     const int ql = threadIdx.x & 63, sg = threadIdx.x >> 6;
     const long n4 = n >> 2;
     for (long b = (long)blockIdx.x * 64; b < n4; b += (long)gridDim.x * 64) {
@@ -290,6 +289,32 @@ __global__ __launch_bounds__(256) void reduce_slabs_scatter_kernel(const float* 
         }
         __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(256) void reduce_slabs_scatter_kernel(const float* __restrict__ slab, int nsplit,
+                                                                   long slab_stride, float* __restrict__ out, long n,
+                                                                   IndexMap mp, Limits lim, int accumulate) {
+    __shared__ float4 red[4][64];
+    reduce_slabs_scatter_body(slab, nsplit, slab_stride, out, n, mp, lim, accumulate, red);
+}
+
+// several folds in one launch: blockIdx.y selects the job
+struct ReduceJob {
+    const float* slab;
+    float* out;
+    long slab_stride, n;
+    IndexMap mp;
+    Limits lim;
+    int nsplit, accumulate;
+};
+struct ReduceJobs {
+    ReduceJob j[VAE_MAX_REDUCE_JOBS];
+};
+__global__ __launch_bounds__(256) void multi_reduce_slabs_scatter_kernel(const ReduceJobs jobs) {
+    __shared__ float4 red[4][64];
+    const ReduceJob& jb = jobs.j[blockIdx.y];
+    if ((long)blockIdx.x * 64 >= (jb.n >> 2)) return;      // whole workgroup: no barrier is skipped by part of it
+    reduce_slabs_scatter_body(jb.slab, jb.nsplit, jb.slab_stride, jb.out, jb.n, jb.mp, jb.lim, jb.accumulate, red);
 }
 
 // Every weight tensor of the model repacked in ONE launch: blockIdx.y selects the job.  A job is walked in the
@@ -518,6 +543,33 @@ extern "C" int vae_reduce_slabs_scatter(const float* slab, int nsplit, long slab
     hipLaunchKernelGGL(reduce_slabs_scatter_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, slab + slab_base,
                        nsplit, slab_stride, out, n, mp, lim, accumulate);
     VAE_LAUNCH_CHECK("reduce_slabs_scatter_kernel");
+    return 0;
+}
+
+extern "C" int vae_multi_reduce_slabs_scatter(const vae_reduce_job* jobs, int njobs, void* stream) {
+    VAE_CHECK(jobs && njobs > 0 && njobs <= VAE_MAX_REDUCE_JOBS, "vae_multi_reduce_slabs_scatter: njobs=%d out of range (1..%d)",
+              njobs, VAE_MAX_REDUCE_JOBS);
+    ReduceJobs rj;
+    long max_blocks = 1;
+    double bytes = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const vae_reduce_job& q = jobs[i];
+        VAE_CHECK(q.slab && q.out && q.nsplit > 0, "vae_multi_reduce_slabs_scatter: job %d has bad arguments", i);
+        if (int e = make_map(rj.j[i].mp, q.dims, q.strides, q.base, "vae_multi_reduce_slabs_scatter")) return e;
+        rj.j[i].lim = {(int)q.limits[0], (int)q.limits[1], (int)q.limits[2], (int)q.limits[3]};
+        const long n = q.dims[0] * q.dims[1] * q.dims[2] * q.dims[3];
+        VAE_CHECK(n % 4 == 0 && q.slab_stride % 4 == 0 && q.slab_base % 4 == 0 && ((uintptr_t)q.slab & 15) == 0,
+                  "vae_multi_reduce_slabs_scatter: job %d: element count, slab stride and base must be multiples of 4", i);
+        rj.j[i].slab = q.slab + q.slab_base; rj.j[i].out = q.out; rj.j[i].slab_stride = q.slab_stride; rj.j[i].n = n;
+        rj.j[i].nsplit = q.nsplit; rj.j[i].accumulate = q.accumulate;
+        const long blocks = (n / 4 + 63) / 64;
+        if (blocks > max_blocks) max_blocks = blocks;
+        bytes += 4.0 * n * (q.nsplit + 1);
+    }
+    if (max_blocks > 2048) max_blocks = 2048;
+    ProfScope prof("reduce_slabs_scatter_kernel", 0.0, bytes, (hipStream_t)stream);
+    hipLaunchKernelGGL(multi_reduce_slabs_scatter_kernel, dim3((int)max_blocks, njobs), dim3(256), 0, (hipStream_t)stream, rj);
+    VAE_LAUNCH_CHECK("multi_reduce_slabs_scatter_kernel");
     return 0;
 }
 

@@ -184,7 +184,10 @@ void make_ws_layout(const Dims& d, WsLayout* w) {
     w->bnpart = put(1024L * 512 * 4);
     w->headpart = put(1024L * 7 * 64 * 4);
     w->headsums = put(7 * 64 * 4);
-    long s = slab_need(64, 64, 2, npix);
+    // every weight-gradient GEMM of a backward stage keeps its own split-K slabs until the stage's single fold launch:
+    // the buffer holds all of them side by side (a few hundred MB of 288 GB)
+    auto up64 = [](long v) { return (v + 63) / 64 * 64; };
+    long s = up64(slab_need(64, 64, 2, npix));
     for (int i = 0; i < 7; ++i) {
         const int b = (i + 1) / 2;     // encoder block of conv i (c1b -> 0, c2a,c2b -> 1, ...)
         const long h = d.S >> b;
@@ -193,15 +196,14 @@ void make_ws_layout(const Dims& d, WsLayout* w) {
             const long vp = (long)vae_conv3_wgrad_patch_ksplit(d.N, (int)h, (int)h, CONV_CI[i], CONV_CO[i]) * 9 * CONV_CO[i] * CONV_CI[i];
             if (vp > v) v = vp;
         }
-        if (v > s) s = v;
+        s += up64(v);
     }
     for (int u = 0; u < 3; ++u) {
         const long hh = (long)s8 << u;
-        const long v = slab_need(DEC_CO[u], DEC_CI[u], 4, (long)d.N * hh * hh);
-        if (v > s) s = v;
+        s += up64(slab_need(DEC_CO[u], DEC_CI[u], 4, (long)d.N * hh * hh));
     }
-    { const long v = slab_need(2 * d.L, d.F, 1, d.N); if (v > s) s = v; }
-    { const long v = slab_need(d.F, d.L, 1, d.N); if (v > s) s = v; }
+    s += up64(slab_need(2 * d.L, d.F, 1, d.N));
+    s += up64(slab_need(d.F, d.L, 1, d.N));
     w->slab_floats = s;
     w->slab = put(s * 4);
     // split-K slabs of the batch-row nn.Linear layers (main stream; the big slab belongs to the weight-gradient stream)
@@ -463,6 +465,11 @@ struct Fork {
     bool two;
     hipEvent_t* ev;
     int n;
+    // slab folds wait for the end of the backward stage: one launch folds them all (each is a few microseconds of
+    // work that only the optimizer needs); every weight-gradient GEMM of the stage gets its own piece of the slab buffer
+    vae_reduce_job jobs[VAE_MAX_REDUCE_JOBS];
+    int njobs;
+    long slab_used;      // floats
 };
 
 static const int N_EVENTS = 64;
@@ -484,6 +491,8 @@ static int fork_init(Fork* f, void* main, void* side) {
     f->two = side != nullptr && side != main;
     f->side = f->two ? (hipStream_t)side : (hipStream_t)main;
     f->n = 0;
+    f->njobs = 0;
+    f->slab_used = 0;
     f->ev = f->two ? event_pool() : nullptr;
     CHECK(!f->two || f->ev, "vae_model_backward: could not create the events that order the two streams");
     return 0;
@@ -510,21 +519,50 @@ static int main_after(Fork* f, hipEvent_t e) {
     return 0;
 }
 
-static int wgrad_to(const Ctx& c, const void* P, const void* Q, int M, int N, long K, int ldp, int ldq, int mode, int H,
-                    int W, int taps, int* nsplit_out, void* stream) {
+// the next `floats` of the slab buffer
+static int slab_take(const Ctx& c, Fork* f, long floats, float** out) {
+    CHECK(f->slab_used + floats <= c.ws.slab_floats, "vae_model_backward: split-K slab buffer exhausted (internal sizing error)");
+    *out = (float*)c.at(c.ws.slab) + f->slab_used;
+    f->slab_used += (floats + 63) / 64 * 64;
+    return 0;
+}
+// record a fold (arguments as reduce4) for the stage's fold launch
+static int fold_later(Fork* f, const float* slab, int ns, long stride, long slab_base, float* out, long d0, long d1, long d2,
+                      long d3, long s0, long s1, long s2, long s3, long l1 = -1, long l2 = -1) {
+    CHECK(f->njobs < VAE_MAX_REDUCE_JOBS, "vae_model_backward: too many pending slab folds");
+    vae_reduce_job& q = f->jobs[f->njobs++];
+    q.slab = slab; q.nsplit = ns; q.slab_stride = stride; q.slab_base = slab_base; q.out = out; q.base = 0; q.accumulate = 0;
+    q.dims[0] = d0; q.dims[1] = d1; q.dims[2] = d2; q.dims[3] = d3;
+    q.strides[0] = s0; q.strides[1] = s1; q.strides[2] = s2; q.strides[3] = s3;
+    q.limits[0] = d0; q.limits[1] = l1 < 0 ? d1 : l1; q.limits[2] = l2 < 0 ? d2 : l2; q.limits[3] = d3;
+    return 0;
+}
+// fold everything recorded so far, on the stream the weight gradients run on; the slab buffer is free again after it
+static int flush_folds(Fork* f) {
+    if (f->njobs > 0) TRY(vae_multi_reduce_slabs_scatter(f->jobs, f->njobs, f->side));
+    f->njobs = 0;
+    f->slab_used = 0;
+    return 0;
+}
+
+static int wgrad_to(const Ctx& c, Fork* f, float** slab_out, const void* P, const void* Q, int M, int N, long K, int ldp,
+                    int ldq, int mode, int H, int W, int taps, int* nsplit_out, void* stream) {
     const int ns = vae_wgrad_ksplit(M, N, taps, K);
     *nsplit_out = ns;
-    return vae_wgrad_gemm(P, Q, (float*)c.at(c.ws.slab), M, N, K, ldp, ldq, mode, H, W, ns, stream);
+    TRY(slab_take(c, f, (long)ns * taps * M * N, slab_out));
+    return vae_wgrad_gemm(P, Q, *slab_out, M, N, K, ldp, ldq, mode, H, W, ns, stream);
 }
 
 // 3x3 conv weight gradient into the slab: nine-taps-per-workgroup kernel where it applies
-static int conv3_wgrad_to(const Ctx& c, const void* dy, const void* x, int Co, int Ci, int H, int* nsplit_out, void* stream) {
+static int conv3_wgrad_to(const Ctx& c, Fork* f, float** slab_out, const void* dy, const void* x, int Co, int Ci, int H,
+                          int* nsplit_out, void* stream) {
     if (vae_conv3_wgrad_patch_ok(H, H, Ci, Co)) {
         const int ns = vae_conv3_wgrad_patch_ksplit(c.d.N, H, H, Ci, Co);
         *nsplit_out = ns;
-        return vae_conv3_wgrad_patch(dy, x, (float*)c.at(c.ws.slab), c.d.N, H, H, Ci, Co, ns, stream);
+        TRY(slab_take(c, f, (long)ns * 9 * Co * Ci, slab_out));
+        return vae_conv3_wgrad_patch(dy, x, *slab_out, c.d.N, H, H, Ci, Co, ns, stream);
     }
-    return wgrad_to(c, dy, x, Co, Ci, (long)c.d.N * H * H, Co, Ci, VAE_WGRAD_CONV3, H, H, 9, nsplit_out, stream);
+    return wgrad_to(c, f, slab_out, dy, x, Co, Ci, (long)c.d.N * H * H, Co, Ci, VAE_WGRAD_CONV3, H, H, 9, nsplit_out, stream);
 }
 
 // stage 0: head .. fc heads (everything after the encoder); leaves d(encoder output) in gradient buffer 0
@@ -536,6 +574,7 @@ static int backward_decoder(const Ctx& c, Fork* f, const float* d_recon, const f
     const int s8 = d.S / 8;
     void* sd = f->side;
     int ns = 1;
+    float* slab = nullptr;
     // 1x1 head + bn1
     // [d gamma1 | d beta1] and [d head.weight | d head.bias] are adjacent in the flat layout
     TRY(vae_head_bwd(d_recon, recon, c.at(w.yd[2]), c.coef(10, 0), c.coef(10, 1), c.coef(10, 2), c.coef(10, 3),
@@ -551,9 +590,9 @@ static int backward_decoder(const Ctx& c, Fork* f, const float* d_recon, const f
         const int Ci = DEC_CI[u], Co = DEC_CO[u];
         const void* xin = u == 0 ? c.at(w.h) : c.at(w.ad[u - 1]);
         TRY(side_after_main(f));
-        TRY(wgrad_to(c, c.at(w.g[x]), xin, Co, Ci, Min, Co, Ci, VAE_WGRAD_CONVT, hh, hh, 4, &ns, sd));
+        TRY(wgrad_to(c, f, &slab, c.at(w.g[x]), xin, Co, Ci, Min, Co, Ci, VAE_WGRAD_CONVT, hh, hh, 4, &ns, sd));
         // slab [co][tap][ci] -> ConvTranspose2d weight [ci][co][tap]
-        TRY(reduce4((float*)c.at(w.slab), ns, 4L * Co * Ci, 0, c.G(P_UP3_W + 4 * u), Co, 4, Ci, 1, 4, 1, 4L * Co, 0, sd));
+        TRY(fold_later(f, slab, ns, 4L * Co * Ci, 0, c.G(P_UP3_W + 4 * u), Co, 4, Ci, 1, 4, 1, 4L * Co, 0));
         hipEvent_t w_this;
         TRY(side_mark(f, &w_this));
         // (the bias in front of a train-mode BatchNorm has an identically zero gradient: its slot is left as it is)
@@ -576,9 +615,9 @@ static int backward_decoder(const Ctx& c, Fork* f, const float* d_recon, const f
     // fc_up.bias grad: column sums, NHWC order -> parameter order via a permuting reduce
     TRY(reduce4((float*)c.at(w.colp), nr, d.F, 0, c.G(P_FC_UP_B), 1, d.hw, 256, 1, 0, 1, d.hw, 0, c.stream));
     TRY(side_after_main(f));
-    TRY(wgrad_to(c, c.at(w.dpre), c.at(w.zb), d.F, d.L, d.N, d.F, d.L, VAE_WGRAD_PLAIN, 1, 1, 1, &ns, sd));
+    TRY(wgrad_to(c, f, &slab, c.at(w.dpre), c.at(w.zb), d.F, d.L, d.N, d.F, d.L, VAE_WGRAD_PLAIN, 1, 1, 1, &ns, sd));
     // slab [(p, c)][l] -> fc_up.weight [(c, p)][l]
-    TRY(reduce4((float*)c.at(w.slab), ns, (long)d.F * d.L, 0, c.G(P_FC_UP_W), d.hw, 256, d.L, 1, d.L, (long)d.hw * d.L, 1, 0, sd));
+    TRY(fold_later(f, slab, ns, (long)d.F * d.L, 0, c.G(P_FC_UP_W), d.hw, 256, d.L, 1, d.L, (long)d.hw * d.L, 1, 0));
     TRY(linear_f32(c, c.at(w.dpre), c.pk_at(c.pk.up_d), nullptr, (float*)c.at(w.dz), nullptr, d.N, d.L, d.F, VAE_EPI_F32));
     TRY(vae_reparam_kl_bwd((const float*)c.at(w.dz), mu, logvar, eps_in, dmu_ext, dlv_ext, kl_scale, (float*)c.at(w.dmu),
                            (float*)c.at(w.dlv), c.at(w.dcat), (long)d.N * d.L, d.L, c.cfg->seed, c.cfg->step, c.cfg->rank,
@@ -586,11 +625,12 @@ static int backward_decoder(const Ctx& c, Fork* f, const float* d_recon, const f
     TRY(vae_sum_partials((const float*)c.at(w.dmu), d.N, d.L, c.G(P_FC_MU_B), 1.0f, c.stream));
     TRY(vae_sum_partials((const float*)c.at(w.dlv), d.N, d.L, c.G(P_FC_LV_B), 1.0f, c.stream));
     TRY(side_after_main(f));
-    TRY(wgrad_to(c, c.at(w.dcat), c.at(w.ob[3]), 2 * d.L, d.F, d.N, 2 * d.L, d.F, VAE_WGRAD_PLAIN, 1, 1, 1, &ns, sd));
+    TRY(wgrad_to(c, f, &slab, c.at(w.dcat), c.at(w.ob[3]), 2 * d.L, d.F, d.N, 2 * d.L, d.F, VAE_WGRAD_PLAIN, 1, 1, 1, &ns, sd));
     for (int t = 0; t < 2; ++t)
         // slab rows [t*L, (t+1)*L) x columns (p, c) -> fc weight [l][(c, p)]
-        TRY(reduce4((float*)c.at(w.slab), ns, 2L * d.L * d.F, (long)t * d.L * d.F, c.G(t ? P_FC_LV_W : P_FC_MU_W), d.L, d.hw,
-                    256, 1, d.F, 1, d.hw, 0, sd));
+        TRY(fold_later(f, slab, ns, 2L * d.L * d.F, (long)t * d.L * d.F, c.G(t ? P_FC_LV_W : P_FC_MU_W), d.L, d.hw, 256, 1,
+                       d.F, 1, d.hw, 0));
+    TRY(flush_folds(f));
     // d(encoder output) [N][F] bf16 -> buffer 0 (its last reader, the first ConvT wgrad, is behind the events waited above)
     TRY(main_after(f, w_prev));
     return vae_linear_gemm(c.at(w.dcat), c.pk_at(c.pk.fc_d), nullptr, c.at(w.g[0]), nullptr, nullptr, nullptr, d.N, d.F,
@@ -614,9 +654,10 @@ static int backward_block(const Ctx& c, Fork* f, int b, const void* const* masks
                              b < 3 ? c.at(w.route[b]) : nullptr, d.N, H, H, C, b < 3, p, masks ? masks[b] : nullptr,
                              c.cfg->seed, c.cfg->step, VAE_STREAM_DROPOUT0 + b, c.cfg->rank, c.stream));
     TRY(side_after_main(f));
-    TRY(conv3_wgrad_to(c, c.at(w.g[ib]), c.at(w.aa[b]), C, C, H, &ns, sd));
+    float* slab = nullptr;
+    TRY(conv3_wgrad_to(c, f, &slab, c.at(w.g[ib]), c.at(w.aa[b]), C, C, H, &ns, sd));
     // slab [co][tap][ci] -> Conv2d weight [co][ci][tap]
-    TRY(reduce4((float*)c.at(w.slab), ns, 9L * C * C, 0, c.G(8 * b + 4), C, 9, C, 1, 9L * C, 1, 9, 0, sd));
+    TRY(fold_later(f, slab, ns, 9L * C * C, 0, c.G(8 * b + 4), C, 9, C, 1, 9L * C, 1, 9, 0));
     hipEvent_t w1;
     TRY(side_mark(f, &w1));
     TRY(main_after(f, *w_carry));       // buffer c was read by the previous block's second wgrad
@@ -627,14 +668,14 @@ static int backward_block(const Ctx& c, Fork* f, int b, const void* const* masks
                        (float*)c.at(w.bnpart), c.G(8 * b + 2), c.at(w.g[ia]), d.N, H, H, C, 0, 0.0, nullptr, 0, 0, 0, 0, c.stream));
     TRY(side_after_main(f));
     if (b == 0) {
-        TRY(wgrad_to(c, c.at(w.g[ia]), c.at(w.x8), C, 64, M, C, 8, VAE_WGRAD_CONV3_C8, H, H, 2, &ns, sd));
+        TRY(wgrad_to(c, f, &slab, c.at(w.g[ia]), c.at(w.x8), C, 64, M, C, 8, VAE_WGRAD_CONV3_C8, H, H, 2, &ns, sd));
         // slab [co][16 taps][8 ch] (taps >= 9, channels >= Cin are padding) -> weight [co][ci][tap]
-        TRY(reduce4((float*)c.at(w.slab), ns, 64L * 128, 0, c.G(0), 64, 16, 8, 1, 9L * d.Cin, 1, 9, 0, sd, 9, d.Cin));
+        TRY(fold_later(f, slab, ns, 64L * 128, 0, c.G(0), 64, 16, 8, 1, 9L * d.Cin, 1, 9, 0, 9, d.Cin));
         return side_mark(f, w_carry);
     }
     const int Ci = ENC_C[b - 1];
-    TRY(conv3_wgrad_to(c, c.at(w.g[ia]), c.at(w.ob[b - 1]), C, Ci, H, &ns, sd));
-    TRY(reduce4((float*)c.at(w.slab), ns, 9L * C * Ci, 0, c.G(8 * b), C, 9, Ci, 1, 9L * Ci, 1, 9, 0, sd));
+    TRY(conv3_wgrad_to(c, f, &slab, c.at(w.g[ia]), c.at(w.ob[b - 1]), C, Ci, H, &ns, sd));
+    TRY(fold_later(f, slab, ns, 9L * C * Ci, 0, c.G(8 * b), C, 9, Ci, 1, 9L * Ci, 1, 9, 0));
     TRY(side_mark(f, w_carry));
     TRY(main_after(f, w1));             // buffer b is still read by this block's first wgrad
     return vae_conv3x3_gemm(c.at(w.g[ia]), c.pk_at(c.pk.conv_d[2 * b - 1]), nullptr, c.at(w.g[ib]), nullptr, nullptr, d.N, H, H,
@@ -659,10 +700,12 @@ extern "C" int vae_model_backward(const vae_model_cfg* cfg, const float* params,
     if (stage == -1 || stage == 1) {
         TRY(backward_block(c, &f, 3, keep_masks, &carry));
         TRY(backward_block(c, &f, 2, keep_masks, &carry));
+        TRY(flush_folds(&f));
     }
     if (stage == -1 || stage == 2) {
         TRY(backward_block(c, &f, 1, keep_masks, &carry));
         TRY(backward_block(c, &f, 0, keep_masks, &carry));
+        TRY(flush_folds(&f));
     }
     // join: whatever the caller enqueues next on `stream` (all-reduce of this stage, the optimizer) sees every gradient
     hipEvent_t last;
