@@ -55,8 +55,7 @@ def test_construction_matches_reference(name):
     assert m.flat_params.numel() >= sum(p.numel() for p in m.parameters())
 
 
-# What an end-to-end comparison of a bf16 pipeline can and cannot show (measured, see DESIGN.md
-# "Parity"):
+# What an end-to-end comparison of a bf16 pipeline can and cannot show (measured):
 #  * Every kernel is checked on its own, tightly, in test_gpu_kernels*.py (same bf16 operands ->
 #    only fp32 summation order and one output rounding differ).
 #  * End to end, bf16 rounding noise is AMPLIFIED by the network itself: each conv+BatchNorm block
