@@ -199,9 +199,11 @@ __global__ __launch_bounds__(512, 1) void conv3_wgrad_patch_kernel(const PatchP 
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 if (t + 1 < 9) qa[(t + 1) & 1] = q_frag(sbase, kk, t + 1);
+                __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[t & 1], pb[j], acc[t][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
             }
             if (kk == 0 && grp == 1 && kt + 2 < kt_end) stage((it + 1) & 1, kt + 2);
         }
