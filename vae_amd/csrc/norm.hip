@@ -77,19 +77,21 @@ __device__ __forceinline__ void act8(const float y[8], const float sc[8], const 
 
 // ---------------------------------------------------------------------------------------
 // batch statistics -> scale / shift / mean / rstd (+ running stats), one pass over the
-// per-workgroup partials left by the GEMM epilogue.  grid = ceil(C/32), block = 1024.
+// per-workgroup partials left by the GEMM epilogue.  grid = ceil(C/8), block = 1024 = 8 channels x 128 row
+// groups: the launch is latency-bound, so the few hundred KB of partials are spread over as many CUs as there are
+// 32-byte column slices.
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(
     const float* __restrict__ psum, const float* __restrict__ psq, int rows, int C, int fold, double count,
     const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ running_mean,
     float* __restrict__ running_var, float momentum, float eps, int use_running, float* __restrict__ scale,
     float* __restrict__ shift, float* __restrict__ mean_out, float* __restrict__ rstd_out) {
-    __shared__ double red[2][32][33];
-    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;     // 32 channels x 32 row groups
-    const int c = blockIdx.x * 32 + cl;
+    __shared__ double red[2][128][9];
+    const int cl = threadIdx.x & 7, rg = threadIdx.x >> 3;      // 8 channels x 128 row groups
+    const int c = blockIdx.x * 8 + cl;
     double s = 0.0, q = 0.0;
     if (!use_running && c < C) {
         const int ncols = fold * C;
-        for (int r = rg; r < rows; r += 32)
+        for (int r = rg; r < rows; r += 128)
             for (int t = 0; t < fold; ++t) {
                 s += (double)psum[(long)r * ncols + t * C + c];
                 q += (double)psq[(long)r * ncols + t * C + c];
@@ -98,6 +100,14 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(
     red[0][rg][cl] = s;
     red[1][rg][cl] = q;
     __syncthreads();
+    if (rg < 8) {          // fixed-order tree: 128 row groups -> 8 -> 1
+        s = 0.0; q = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { s += red[0][rg + 8 * i][cl]; q += red[1][rg + 8 * i][cl]; }
+    }
+    __syncthreads();
+    if (rg < 8) { red[0][rg][cl] = s; red[1][rg][cl] = q; }
+    __syncthreads();
     if (rg == 0 && c < C) {
         float mean, var;
         if (use_running) {
@@ -105,7 +115,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(
             var = running_var[c];
         } else {
 #pragma unroll
-            for (int i = 1; i < 32; ++i) { s += red[0][i][cl]; q += red[1][i][cl]; }
+            for (int i = 1; i < 8; ++i) { s += red[0][i][cl]; q += red[1][i][cl]; }
             const double m = s / count;
             double v = q / count - m * m;
             if (v < 0.0) v = 0.0;
@@ -630,7 +640,7 @@ extern "C" int vae_bn_finalize(float* stat_sum, float* stat_sq, int rows, int C,
     VAE_CHECK(use_running ? (running_mean && running_var) : (stat_sum && stat_sq && rows > 0 && count > 0),
               "vae_bn_finalize: missing statistics input");
     VAE_CHECK(C > 0 && fold > 0, "vae_bn_finalize: bad C=%d fold=%d", C, fold);
-    if (!use_running && rows > 512) {
+    if (!use_running && (long)rows * fold > 1024) {
         // many partial rows: fold them to 32 scratch rows with the whole chip first
         const int ncols = fold * C;
         hipLaunchKernelGGL(stats_stage1_kernel, dim3((ncols + 63) / 64, VAE_STAT_SCRATCH_ROWS), dim3(256), 0,
@@ -640,7 +650,7 @@ extern "C" int vae_bn_finalize(float* stat_sum, float* stat_sq, int rows, int C,
         stat_sq += (long)rows * ncols;
         rows = VAE_STAT_SCRATCH_ROWS;
     }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, stat_sum, stat_sq,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 7) / 8), dim3(1024), 0, (hipStream_t)stream, stat_sum, stat_sq,
                        rows, C, fold, count, gamma, beta, running_mean, running_var, momentum, eps, use_running, scale,
                        shift, mean, rstd);
     VAE_LAUNCH_CHECK("bn_finalize_kernel");
