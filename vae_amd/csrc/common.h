@@ -44,8 +44,11 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
     __bf16 b = (__bf16)f;
     return __builtin_bit_cast(unsigned short, b);
 }
+// two at once: the vector cast is ONE v_cvt_pk_bf16_f32 (packing two scalar casts costs four instructions)
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+    const bf16x2v v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(uint32_t, v);
 }
 
 // Workgroup barrier for kernels that keep global->LDS copies (buffer_load ... lds) in flight across it.

@@ -80,12 +80,14 @@ __global__ __launch_bounds__(256, pt_wgs(W, BN)) void conv3_patch_tn_kernel(cons
     constexpr int Q_INSTR = (pt_rows(W) / 8 + 3) / 4;           // patch copies per wave
     // weight tiles sit in a ring as deep as the workgroup's share of the CU's 160 KB allows, at most 4
     constexpr int LDS_SHARE = (163840 / pt_wgs(W, BN)) / 1280 * 1280;     // whole allocation granules
-    constexpr int DEPTH = (LDS_SHARE - 2048 - Q_BYTES) / B_BYTES >= 4 ? 4 : (LDS_SHARE - 2048 - Q_BYTES) / B_BYTES;
+    constexpr int AUX_BYTES = 2048 + BN * 4;                       // statistics accumulators + the bias row
+    constexpr int DEPTH = (LDS_SHARE - AUX_BYTES - Q_BYTES) / B_BYTES >= 4 ? 4 : (LDS_SHARE - AUX_BYTES - Q_BYTES) / B_BYTES;
     static_assert(TN == 64, "wave tile is 64 channels wide");
     static_assert(DEPTH >= 2, "ring depth");
 
     constexpr int RED_BYTES = 2 * WAVES_M * BN * 4;                // statistics accumulators
-    __shared__ __attribute__((aligned(16))) unsigned char smem[Q_BYTES + DEPTH * B_BYTES + RED_BYTES];
+    static_assert(RED_BYTES + BN * 4 == AUX_BYTES, "auxiliary LDS size");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[Q_BYTES + DEPTH * B_BYTES + AUX_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: addresses and branches built on it stay scalar
@@ -183,6 +185,10 @@ __global__ __launch_bounds__(256, pt_wgs(W, BN)) void conv3_patch_tn_kernel(cons
     const bool want_stats = p.stat_sum != nullptr;
     float* red = (float*)(smem + Q_BYTES + DEPTH * B_BYTES);
     for (int i = tid; i < 2 * WAVES_M * BN; i += 256) red[i] = 0.f;     // first read is many barriers away
+    // the bias row sits in LDS for the life of the workgroup: a global load at the top of every epilogue would expose
+    // a memory round trip per tile
+    float* bias_lds = red + 2 * WAVES_M * BN;
+    if (tid < BN) bias_lds[tid] = (p.bias && n0 + tid < p.N) ? p.bias[n0 + tid] : 0.f;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     if (tile != (int)blockIdx.x) barrier_keep_copies();  // the previous tile's patch and weight tiles are done with
     m0 = tile * PT_BM;
@@ -248,13 +254,8 @@ __global__ __launch_bounds__(256, pt_wgs(W, BN)) void conv3_patch_tn_kernel(cons
     float bv[FN][4];     // (re)loaded per tile: 16 registers that need not live through the K loop
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
-        const int n = n0 + wn * TN + j * 16 + (lane >> 4) * 4;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bv[j][r] = 0.f;
-        if (p.bias && n < p.N) {
-            const float4 b4 = *(const float4*)(p.bias + n);
-            bv[j][0] = b4.x; bv[j][1] = b4.y; bv[j][2] = b4.z; bv[j][3] = b4.w;
-        }
+        const float4 b4 = *(const float4*)(bias_lds + wn * TN + j * 16 + (lane >> 4) * 4);
+        bv[j][0] = b4.x; bv[j][1] = b4.y; bv[j][2] = b4.z; bv[j][3] = b4.w;
     }
     float ssum[FN][4], ssq[FN][4];
 #pragma unroll
