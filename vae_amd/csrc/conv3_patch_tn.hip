@@ -269,6 +269,7 @@ __global__ __launch_bounds__(256, pt_wgs(W, BN)) void conv3_patch_tn_kernel(cons
     constexpr int OROW = BN * 2 + 16;
     static_assert(PT_BM * OROW <= Q_BYTES + DEPTH * B_BYTES, "output tile does not fit the staging buffers");
     barrier_keep_copies();                     // every wave is done reading the patch and the weight ring
+    const bool full = m0 + PT_BM <= p.M && n0 + BN <= p.N;
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         const int ml = wm * TM + i * 16 + (lane & 15);
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(256, pt_wgs(W, BN)) void conv3_patch_tn_kernel(cons
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bv[j][r];
-            if (m < p.M && n0 + nl < p.N) {
+            if (full || (m < p.M && n0 + nl < p.N)) {      // `full` is uniform: no per-element predicate on whole tiles
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     ssum[j][r] += v[r];
@@ -301,18 +302,25 @@ __global__ __launch_bounds__(256, pt_wgs(W, BN)) void conv3_patch_tn_kernel(cons
         }
     }
     if (want_stats) {
+        // all 16-lane sums first (32 independent DPP chains the scheduler can interleave), then one predicated block
 #pragma unroll
         for (int j = 0; j < FN; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float s = pt_row16_sum(ssum[j][r]), q = pt_row16_sum(ssq[j][r]);
-                if ((lane & 15) == 0) {              // the one lane that owns this (wave row, channel) slot
+                ssum[j][r] = pt_row16_sum(ssum[j][r]);
+                ssq[j][r] = pt_row16_sum(ssq[j][r]);
+            }
+        if ((lane & 15) == 0) {                      // the one lane that owns a (wave row, channel) slot
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
                     const int cc = wn * TN + j * 16 + (lane >> 4) * 4 + r;
                     // ds_add_f32 without return: fire and forget (a read-modify-write would wait ~100 cycles per slot)
-                    (void)__hip_atomic_fetch_add(&red[wm * BN + cc], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    (void)__hip_atomic_fetch_add(&red[(WAVES_M + wm) * BN + cc], q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    (void)__hip_atomic_fetch_add(&red[wm * BN + cc], ssum[j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    (void)__hip_atomic_fetch_add(&red[(WAVES_M + wm) * BN + cc], ssq[j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
-            }
+        }
     }
     }   // tile loop
 
