@@ -212,6 +212,19 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // the bias row is requested before the first tile: a load at the top of the epilogue would expose a memory round
+    // trip in every workgroup, and short-K launches are little more than prologue + epilogue
+    float bv[FN][4];
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int n = n0 + wn * TN + j * 16 + (lane >> 4) * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[j][r] = 0.f;
+        if (p.bias && n < p.N) {
+            const float4 b4 = *(const float4*)(p.bias + (EPI == E_CONVT ? n % p.Co : n));
+            bv[j][0] = b4.x; bv[j][1] = b4.y; bv[j][2] = b4.z; bv[j][3] = b4.w;
+        }
+    }
     // split-K (E_F32 only): workgroup z covers K-steps [z * ksteps, ...) and writes slab z of the output
     const int ks0 = p.ksteps > 0 ? (int)blockIdx.z * p.ksteps : 0;
     const int nk = p.ksteps > 0 ? min(p.ksteps, p.K / BK - ks0) : p.K / BK;
@@ -261,17 +274,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) ssum[j][r] = ssq[j][r] = 0.f;
 
-    float bv[FN][4];
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-        const int n = n0 + wn * TN + j * 16 + (lane >> 4) * 4;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bv[j][r] = 0.f;
-        if (p.bias && n < p.N) {
-            const float4 b4 = *(const float4*)(p.bias + (EPI == E_CONVT ? n % p.Co : n));
-            bv[j][0] = b4.x; bv[j][1] = b4.y; bv[j][2] = b4.z; bv[j][3] = b4.w;
-        }
-    }
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         const int m = m0 + wm * TM + i * 16 + (lane & 15);
@@ -317,17 +319,24 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
     if (want_stats) {
         __syncthreads();   // every wave is done reading the staging buffers
         float* red = (float*)smem;   // [2][WAVES_M][BN]
+        // all 16-lane sums first (independent DPP chains), then one predicated block of LDS stores
 #pragma unroll
         for (int j = 0; j < FN; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float s = row16_sum(ssum[j][r]), q = row16_sum(ssq[j][r]);
-                if ((lane & 15) == 0) {
-                    const int c = wn * TN + j * 16 + (lane >> 4) * 4 + r;
-                    red[wm * BN + c] = s;
-                    red[(WAVES_M + wm) * BN + c] = q;
-                }
+                ssum[j][r] = row16_sum(ssum[j][r]);
+                ssq[j][r] = row16_sum(ssq[j][r]);
             }
+        if ((lane & 15) == 0) {
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = wn * TN + j * 16 + (lane >> 4) * 4 + r;
+                    red[wm * BN + c] = ssum[j][r];
+                    red[(WAVES_M + wm) * BN + c] = ssq[j][r];
+                }
+        }
         __syncthreads();
         if (tid < BN && n0 + tid < p.N) {
             float s = 0.f, q = 0.f;
