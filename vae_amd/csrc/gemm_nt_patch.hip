@@ -182,9 +182,10 @@ __global__ __launch_bounds__(512, 1) void conv3_wgrad_patch_kernel(const PatchP 
         if (grp == 0 && kt + 2 < kt_end) stage((it + 1) & 1, kt + 2);
         if (kt >= kt_end) continue;                       // odd tile count: group 1 idles in the last round
         const unsigned char* sbase = smem + (2 * (it & 1) + grp) * STAGE;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 pb[4];
+        // dY fragments of both halves of the tile: the second half's are requested while the first half's last taps
+        // run, so only the first read of a round exposes its LDS latency
+        bf16x8 pb[2][4];
+        auto load_pb = [&](int kk) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 int alo = p_addr[kk][0], ahi = p_addr[kk][1];
@@ -192,17 +193,22 @@ __global__ __launch_bounds__(512, 1) void conv3_wgrad_patch_kernel(const PatchP 
                     asm volatile("v_xor_b32 %0, %1, %2" : "=v"(alo) : "n"(j << 5), "v"(p_addr[kk][0]));
                     asm volatile("v_xor_b32 %0, %1, %2" : "=v"(ahi) : "n"(j << 5), "v"(p_addr[kk][1]));
                 }
-                pb[j] = tr_pair(sbase + alo, sbase + ahi);
+                pb[kk][j] = tr_pair(sbase + alo, sbase + ahi);
             }
+        };
+        load_pb(0);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
             bf16x8 qa[2];
             qa[0] = q_frag(sbase, kk, 0);
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 if (t + 1 < 9) qa[(t + 1) & 1] = q_frag(sbase, kk, t + 1);
+                if (kk == 0 && t == 6) load_pb(1);
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[t & 1], pb[j], acc[t][j], 0, 0, 0);
+                    acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[t & 1], pb[kk][j], acc[t][j], 0, 0, 0);
                 __builtin_amdgcn_s_setprio(0);
             }
             if (kk == 0 && grp == 1 && kt + 2 < kt_end) stage((it + 1) & 1, kt + 2);
