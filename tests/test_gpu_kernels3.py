@@ -80,6 +80,47 @@ def test_reduce_slabs_scatter_and_multi_pack(L):
     assert torch.equal(bp.cpu(), b.view(3, 4).t().reshape(-1))
 
 
+def test_multi_reduce_equals_the_single_folds(L):
+    """several slab folds in one launch: bit-identical to the one-at-a-time calls (same kernel body, same order)"""
+    g = torch.Generator().manual_seed(23)
+
+    class RJob(ctypes.Structure):
+        _fields_ = [("slab", ctypes.c_void_p), ("nsplit", ctypes.c_int), ("slab_stride", ctypes.c_long),
+                    ("slab_base", ctypes.c_long), ("out", ctypes.c_void_p), ("dims", ctypes.c_long * 4),
+                    ("strides", ctypes.c_long * 4), ("limits", ctypes.c_long * 4), ("base", ctypes.c_long),
+                    ("accumulate", ctypes.c_int)]
+
+    l4 = lambda *v: (ctypes.c_long * 4)(*v)
+    shapes = [(7, 64, 9, 64), (3, 8, 9, 16), (16, 128, 4, 256), (2, 64, 16, 8)]
+    slabs = [torch.randn(*s, generator=g).to(DEV) for s in shapes]
+    specs = []       # (dims, strides, limits, out shape)
+    for (S, Co, T, Ci) in shapes:
+        if T == 16:      # padded first-conv layout [co][16][8] -> [co][3][9]: taps < 9, channels < 3
+            specs.append((l4(Co, 16, 8, 1), l4(27, 1, 9, 0), l4(Co, 9, 3, 1), (Co, 3, 9)))
+        else:            # [co][tap][ci] -> [co][ci][tap]
+            specs.append((l4(Co, T, Ci, 1), l4(T * Ci, 1, T, 0), l4(Co, T, Ci, 1), (Co, Ci, T)))
+    singles, multis = [], []
+    jobs = (RJob * len(shapes))()
+    for i, ((S, Co, T, Ci), sl, (dims, strides, limits, oshape)) in enumerate(zip(shapes, slabs, specs)):
+        o1 = torch.zeros(oshape, device=DEV)
+        L.call("vae_reduce_slabs_scatter", L.ptr(sl), S, Co * T * Ci, 0, L.ptr(o1), dims, strides, limits, 0, 0, L.current_stream())
+        singles.append(o1)
+        o2 = torch.zeros(oshape, device=DEV)
+        multis.append(o2)
+        jobs[i] = RJob(sl.data_ptr(), S, Co * T * Ci, 0, o2.data_ptr(), dims, strides, limits, 0, 0)
+    L.call("vae_multi_reduce_slabs_scatter", jobs, len(shapes), L.current_stream())
+    for (S, Co, T, Ci), sl, a, b in zip(shapes, slabs, singles, multis):
+        assert torch.equal(a, b)
+        ref = sl.double().sum(0)
+        ref = ref[:, :9, :3].permute(0, 2, 1) if T == 16 else ref.permute(0, 2, 1)
+        assert rel_l2(b.cpu(), ref.float().cpu()) <= 1e-6
+    with pytest.raises(RuntimeError, match="out of range"):
+        L.call("vae_multi_reduce_slabs_scatter", jobs, 0, L.current_stream())
+    jobs[1].nsplit = 0
+    with pytest.raises(RuntimeError, match="bad arguments"):
+        L.call("vae_multi_reduce_slabs_scatter", jobs, 2, L.current_stream())
+
+
 @pytest.mark.parametrize("n", [4096 * 997 + 3, 1000])
 def test_adamw_clip_step_matches_oracle(L, n):
     g = torch.Generator().manual_seed(n)
