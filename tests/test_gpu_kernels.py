@@ -166,7 +166,10 @@ def check_bf16(got, ref, what):
                                          # patch-staged kernel geometries: 8 / 2 / 4 images per tile, a ragged last tile,
                                          # 64-wide rows, several channel chunks with 256 outputs
                                          (2048, 4, 4, 64, 128), (513, 8, 8, 128, 64), (1024, 8, 4, 64, 64),
-                                         (8, 64, 64, 64, 64), (40, 32, 32, 128, 256)])
+                                         (8, 64, 64, 64, 64), (40, 32, 32, 128, 256),
+                                         # enough 64-channel work for the 256-pixel tiles: four 8x8 images, one 16x16 image,
+                                         # 8 rows of 32, 4 rows of 64 per tile; two channel chunks
+                                         (2048, 8, 8, 64, 64), (512, 16, 16, 128, 64), (128, 32, 32, 64, 64), (32, 64, 64, 64, 64)])
 def test_conv3x3_fwd_dgrad(L, n, H, W, Ci, Co):
     g = torch.Generator().manual_seed(n + H + Ci)
     x = bf(torch.randn(n, Ci, H, W, generator=g))

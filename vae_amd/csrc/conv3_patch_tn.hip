@@ -43,12 +43,17 @@ struct PatchTN {
     float inv_per;        // 1 / ((R + 2) * (W + 2))
 };
 
-constexpr int PT_BM = 128;
+// pixels per tile: 128, or 256 with the 64-channel tile (the mirror image of 128 pixels x 128 channels: the same
+// 64 x 64 wave tiles, and the per-tile costs -- weight copies, barriers, prologue, statistics -- paid half as often)
 constexpr int PT_ROWB = 128;
 // patch rows reserved in LDS per image width (the largest patch any covered H gives, rounded up to 8):
 // W=4: 8 images of 4x4 = 8*6*6; W=8: 2 images of 8x8 = 2*10*10; W=16: 2 images of 4x16 = 2*6*18;
 // W=32: 4 rows = 6*34; W=64: 2 rows = 4*66
-constexpr int pt_rows(int W) { return W == 4 ? 288 : W == 8 ? 200 : W == 16 ? 216 : W == 32 ? 208 : 264; }
+// 256-pixel tiles: 4 images of 8x8 = 4*10*10; one 16x16 image = 18*18 (rounded up to 8); 8 rows of 32 = 10*34; 4 rows of 64 = 6*66
+constexpr int pt_rows(int W, int BM = 128) {
+    return BM == 128 ? (W == 4 ? 288 : W == 8 ? 200 : W == 16 ? 216 : W == 32 ? 208 : 264)
+                     : (W == 8 ? 400 : W == 16 ? 328 : W == 32 ? 344 : 400);
+}
 
 // s_waitcnt vmcnt(groups * PER) for a wave-uniform runtime group count in [0, 2]
 template <int PER>
@@ -67,19 +72,20 @@ __device__ __forceinline__ float pt_row16_sum(float v) {
 }
 
 // workgroups that share a CU: three of the 64-channel form (a third of the LDS and at most 168 VGPRs each), else two
-constexpr int pt_wgs(int W, int BN) { return BN == 64 && W != 4 ? 3 : 2; }
+constexpr int pt_wgs(int W, int BN, int BM = 128) { return BN == 64 && BM == 128 && W != 4 ? 3 : 2; }
 
-template <int W, int BN>
-__global__ __launch_bounds__(256, pt_wgs(W, BN)) void conv3_patch_tn_kernel(const PatchTN p) {
+template <int W, int BN, int PT_BM>
+__global__ __launch_bounds__(256, pt_wgs(W, BN, PT_BM)) void conv3_patch_tn_kernel(const PatchTN p) {
+    static_assert(PT_BM == 128 || (PT_BM == 256 && BN == 64 && W >= 8), "tile heights: 128, or 256 with the 64-channel tile");
     constexpr int W2 = W + 2;
     constexpr int WAVES_M = BN == 128 ? 2 : 4, WAVES_N = 4 / WAVES_M;
     constexpr int TM = PT_BM / WAVES_M, TN = BN / WAVES_N;      // wave tile: TM pixels x TN channels
     constexpr int FM = TM / 16, FN = TN / 16;
-    constexpr int Q_BYTES = pt_rows(W) * PT_ROWB, B_BYTES = BN * PT_ROWB;
+    constexpr int Q_BYTES = pt_rows(W, PT_BM) * PT_ROWB, B_BYTES = BN * PT_ROWB;
     constexpr int B_INSTR = BN / 8 / 4;
-    constexpr int Q_INSTR = (pt_rows(W) / 8 + 3) / 4;           // patch copies per wave
+    constexpr int Q_INSTR = (pt_rows(W, PT_BM) / 8 + 3) / 4;    // patch copies per wave
     // weight tiles sit in a ring as deep as the workgroup's share of the CU's 160 KB allows, at most 4
-    constexpr int LDS_SHARE = (163840 / pt_wgs(W, BN)) / 1280 * 1280;     // whole allocation granules
+    constexpr int LDS_SHARE = (163840 / pt_wgs(W, BN, PT_BM)) / 1280 * 1280;     // whole allocation granules
     constexpr int AUX_BYTES = 2048 + BN * 4;                       // statistics accumulators + the bias row
     constexpr int DEPTH = (LDS_SHARE - AUX_BYTES - Q_BYTES) / B_BYTES >= 4 ? 4 : (LDS_SHARE - AUX_BYTES - Q_BYTES) / B_BYTES;
     static_assert(TN == 64, "wave tile is 64 channels wide");
@@ -344,9 +350,22 @@ static int pt_ilog2(int v) {
 }
 
 template <int W>
-static void pt_launch_w(const PatchTN& p, dim3 grid, int bn, hipStream_t s) {
-    if (bn == 64) hipLaunchKernelGGL((conv3_patch_tn_kernel<W, 64>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((conv3_patch_tn_kernel<W, 128>), grid, dim3(256), 0, s, p);
+static void pt_launch_w(const PatchTN& p, dim3 grid, int bn, int bm, hipStream_t s) {
+    if constexpr (W >= 8) {
+        if (bm == 256) { hipLaunchKernelGGL((conv3_patch_tn_kernel<W, 64, 256>), grid, dim3(256), 0, s, p); return; }
+    }
+    if (bn == 64) hipLaunchKernelGGL((conv3_patch_tn_kernel<W, 64, 128>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((conv3_patch_tn_kernel<W, 128, 128>), grid, dim3(256), 0, s, p);
+}
+
+// tiles of bm pixels hold whole image rows or whole images, and the patch fits the rows reserved for this width
+static bool pt_geom_ok(int H, int W, int bm) {
+    const long hw = (long)H * W;
+    if (bm == 256 && W < 8) return false;
+    if (hw < bm && (bm % hw || hw < 16)) return false;
+    if (hw >= bm && bm % W) return false;
+    const int R = hw >= bm ? bm / W : H, G = hw >= bm ? 1 : (int)(bm / hw);
+    return G * (R + 2) * (W + 2) <= pt_rows(W, bm);
 }
 
 // 1 when the patch kernel covers the geometry: power-of-two image, 4 <= W <= 64, tiles of 128 pixels that
@@ -354,32 +373,35 @@ static void pt_launch_w(const PatchTN& p, dim3 grid, int bn, hipStream_t s) {
 bool conv3_patch_tn_ok(int n_img, int H, int W, int Cin, int Cout) {
     if (pt_ilog2(H) < 0 || pt_ilog2(W) < 0 || W < 4 || W > 64) return false;
     if (Cin % 64 || Cout % 64) return false;
+    if (!pt_geom_ok(H, W, 128)) return false;
     const long hw = (long)H * W;
-    if (hw < 128 && (128 % hw || hw < 16)) return false;
-    {   // the patch must fit the rows reserved for this width
-        const int R = hw >= 128 ? 128 / W : H, G = hw >= 128 ? 1 : (int)(128 / hw);
-        if (G * (R + 2) * (W + 2) > pt_rows(W)) return false;
-    }
     if ((long)n_img * hw * (Cin > Cout ? Cin : Cout) * 2 >= (1L << 32)) return false;
     if ((long)Cout * 9 * Cin >= (1L << 30)) return false;
     return true;
 }
 
-// workgroups along M (each walks ceil(tiles / gx) pixel tiles) = statistics rows written
-// channel-tile width: 128 where that still gives every CU a workgroup, else 64 (twice the workgroups)
-static int pt_pick_bn(long M, int Cout) {
-    const long ntiles = (M + PT_BM - 1) / PT_BM;
-    return Cout % 128 == 0 && ntiles * (Cout / 128) >= 256 ? 128 : 64;
-}
-
-int conv3_patch_tn_rows(long M, int Cout, int W) {
-    const long ntiles = (M + PT_BM - 1) / PT_BM;
-    const int bn = pt_pick_bn(M, Cout), gy = Cout / bn;
-    long gx = 256 * pt_wgs(W, bn) / gy;      // every CU holds its full share of resident workgroups
+// Tiling of a launch: 128-channel tiles where that still gives every CU a workgroup, else 64 channels; with 64
+// channels, 256-pixel tiles when those still give every CU two workgroups.  gx workgroups along M each walk
+// ceil(tiles / gx) pixel tiles and leave one row of partial statistics.
+struct PtPlan {
+    int bm, bn, gx, gy;
+};
+static PtPlan pt_plan(long M, int H, int W, int Cout) {
+    PtPlan q;
+    const long t128 = (M + 127) / 128;
+    q.bm = 128;
+    q.bn = Cout % 128 == 0 && t128 * (Cout / 128) >= 256 ? 128 : 64;
+    if (q.bn == 64 && (M + 255) / 256 * (Cout / 64) >= 512 && M % 256 == 0 && pt_geom_ok(H, W, 256)) q.bm = 256;
+    const long ntiles = (M + q.bm - 1) / q.bm;
+    q.gy = Cout / q.bn;
+    long gx = 256 * pt_wgs(W, q.bn, q.bm) / q.gy;      // every CU holds its full share of resident workgroups
     if (gx > ntiles) gx = ntiles;
     if (gx < 1) gx = 1;
-    return (int)gx;
+    q.gx = (int)gx;
+    return q;
 }
+
+int conv3_patch_tn_rows(long M, int H, int W, int Cout) { return pt_plan(M, H, W, Cout).gx; }
 
 int conv3_patch_tn_launch(const void* x, const void* w_packed, const float* bias, void* y, float* stat_sum, float* stat_sq,
                           int n_img, int H, int W, int Cin, int Cout, double flops, double bytes, hipStream_t s) {
@@ -387,22 +409,22 @@ int conv3_patch_tn_launch(const void* x, const void* w_packed, const float* bias
     p.A = (const bf16_t*)x; p.B = (const bf16_t*)w_packed; p.bias = bias; p.out = (bf16_t*)y;
     p.stat_sum = stat_sum; p.stat_sq = stat_sq;
     p.M = n_img * H * W; p.N = Cout; p.C = Cin; p.H = H; p.wshift = pt_ilog2(W);
+    const PtPlan plan = pt_plan(p.M, H, W, Cout);
     const long hw = (long)H * W;
-    if (hw >= 128) { p.G = 1; p.R = 128 / W; } else { p.G = (int)(128 / hw); p.R = H; }
+    if (hw >= plan.bm) { p.G = 1; p.R = plan.bm / W; } else { p.G = (int)(plan.bm / hw); p.R = H; }
     p.rwshift = pt_ilog2(p.R * W);
     p.PR = p.G * (p.R + 2) * (W + 2);
     p.inv_per = 1.0f / (float)((p.R + 2) * (W + 2));
-    VAE_CHECK(p.PR <= pt_rows(W) && p.rwshift >= 0, "conv3 patch kernel: internal geometry error (PR=%d)", p.PR);
-    const int bn = pt_pick_bn(p.M, Cout);
-    dim3 grid(conv3_patch_tn_rows(p.M, Cout, W), Cout / bn);
+    VAE_CHECK(p.PR <= pt_rows(W, plan.bm) && p.rwshift >= 0, "conv3 patch kernel: internal geometry error (PR=%d)", p.PR);
+    dim3 grid(plan.gx, plan.gy);
     static char name[2][48] = {"conv3_patch_tn_kernel<64>", "conv3_patch_tn_kernel<128>"};
-    ProfScope prof(name[bn == 128], flops, bytes, s);
+    ProfScope prof(name[plan.bn == 128], flops, bytes, s);
     switch (W) {
-        case 4: pt_launch_w<4>(p, grid, bn, s); break;
-        case 8: pt_launch_w<8>(p, grid, bn, s); break;
-        case 16: pt_launch_w<16>(p, grid, bn, s); break;
-        case 32: pt_launch_w<32>(p, grid, bn, s); break;
-        default: pt_launch_w<64>(p, grid, bn, s); break;
+        case 4: pt_launch_w<4>(p, grid, plan.bn, plan.bm, s); break;
+        case 8: pt_launch_w<8>(p, grid, plan.bn, plan.bm, s); break;
+        case 16: pt_launch_w<16>(p, grid, plan.bn, plan.bm, s); break;
+        case 32: pt_launch_w<32>(p, grid, plan.bn, plan.bm, s); break;
+        default: pt_launch_w<64>(p, grid, plan.bn, plan.bm, s); break;
     }
     VAE_LAUNCH_CHECK("conv3_patch_tn_kernel");
     return 0;
