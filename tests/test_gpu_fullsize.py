@@ -114,3 +114,41 @@ def test_full_size_properties(N, L, S):
     # fused steps on one batch move the loss down (eps and dropout are redrawn every step, so compare ends, not neighbours)
     losses = [float(fs(x)) for _ in range(30)]
     assert all(torch.isfinite(torch.tensor(losses))) and max(losses[-5:]) < losses[0]
+
+
+@pytest.mark.parametrize("N,L,S,p", [(6, 64, 24, 0.1), (3, 64, 40, 0.0), (130, 64, 16, 0.2), (1, 128, 32, 0.1)])
+def test_ragged_shapes_against_the_oracle(N, L, S, p):
+    """image sizes that are not powers of two (the generic kernels), odd batches, a batch of one: train-mode forward,
+    loss and gradients against the oracle with the Philox streams regenerated on the host"""
+    from vae_amd.vae import VAEConv
+    from vae_amd.train import Config, l1_kl_percep_loss
+    torch.manual_seed(5)
+    m = VAEConv(3, 3, L, p, S).to(DEV).train()
+    m.rng_seed, m.rank, m.rng_step = 99, 2, 7
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    x = torch.rand(N, 3, S, S, generator=torch.Generator().manual_seed(N + S))
+    recon, mu, logvar = m(x.to(DEV))
+    eps = torch.from_numpy(O.philox_normal(N * L, 99, O.STREAM_EPS, 7, 2)).view(N, L)
+    masks = None
+    if p > 0:
+        masks = []
+        for b, (C, H) in enumerate([(64, S), (128, S // 2), (256, S // 4), (256, S // 8)]):
+            k = O.philox_keep_mask(N * H * H * C, p, 99, b, 7, 2)
+            masks.append(torch.from_numpy(k).view(N, H, H, C).permute(0, 3, 1, 2))
+    loss_ref, r_ref, mu_ref, lv_ref, g_ref, _ = O.loss_and_grads(x, sd, eps, "l1", 1.0, True, p, masks)
+    assert rel_l2(recon.detach().cpu(), r_ref) <= 2e-2
+    if N > 1:       # a batch of one at 4x4 leaves BatchNorm 16 values per channel: mu / logvar are noise-dominated
+        assert rel_l2(mu.detach().cpu(), mu_ref) <= 8e-2
+    loss = l1_kl_percep_loss(recon, x.to(DEV), mu, logvar, Config(kl_weight=1.0, percep_weight=0.0), None)
+    assert abs(float(loss.detach()) - float(loss_ref)) <= 2e-2 * abs(float(loss_ref))
+    loss.backward()
+    dot = n_got = n_ref = 0.0
+    for name, prm in m.named_parameters():
+        if zero_grad_bias(name):
+            continue
+        got, ref = prm.grad.detach().cpu().flatten().double(), g_ref[name].flatten().double()
+        assert torch.isfinite(got).all(), name
+        dot, n_got, n_ref = dot + float(torch.dot(got, ref)), n_got + float(got.norm() ** 2), n_ref + float(ref.norm() ** 2)
+    total = dot / (n_got * n_ref) ** 0.5
+    print(f"N={N} S={S}: gradient cosine over all parameters {total:.4f}, norm ratio {(n_got / n_ref) ** 0.5:.3f}")
+    assert total >= (0.97 if N > 1 else 0.85) and 0.85 <= (n_got / n_ref) ** 0.5 <= 1.15
