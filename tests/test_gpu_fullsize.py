@@ -116,7 +116,7 @@ def test_full_size_properties(N, L, S):
     assert all(torch.isfinite(torch.tensor(losses))) and max(losses[-5:]) < losses[0]
 
 
-@pytest.mark.parametrize("N,L,S,p", [(6, 64, 24, 0.1), (3, 64, 40, 0.0), (130, 64, 16, 0.2), (1, 128, 32, 0.1)])
+@pytest.mark.parametrize("N,L,S,p", [(6, 64, 24, 0.1), (3, 64, 40, 0.0), (130, 64, 16, 0.2), (1, 128, 32, 0.1), (2, 128, 128, 0.1)])
 def test_ragged_shapes_against_the_oracle(N, L, S, p):
     """image sizes that are not powers of two (the generic kernels), odd batches, a batch of one: train-mode forward,
     loss and gradients against the oracle with the Philox streams regenerated on the host"""
@@ -152,3 +152,19 @@ def test_ragged_shapes_against_the_oracle(N, L, S, p):
     total = dot / (n_got * n_ref) ** 0.5
     print(f"N={N} S={S}: gradient cosine over all parameters {total:.4f}, norm ratio {(n_got / n_ref) ** 0.5:.3f}")
     assert total >= (0.97 if N > 1 else 0.85) and 0.85 <= (n_got / n_ref) ** 0.5 <= 1.15
+
+
+def test_single_channel_input_against_the_oracle():
+    """num_channels: 1 (the MNIST option of the reference's config/local.yaml:12-13): forward against the oracle"""
+    from vae_amd.vae import VAEConv
+    torch.manual_seed(9)
+    m = VAEConv(1, 3, 64, 0.0, 32).to(DEV).train()
+    m.rng_seed, m.rank, m.rng_step = 5, 0, 0
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    x = torch.rand(16, 1, 32, 32, generator=torch.Generator().manual_seed(2))
+    recon, mu, logvar = m(x.to(DEV))
+    eps = torch.from_numpy(O.philox_normal(16 * 64, 5, O.STREAM_EPS, 0, 0)).view(16, 64)
+    with torch.no_grad():
+        r_ref, mu_ref, lv_ref = O.forward(x, sd, eps, True, 0.0, None)
+    assert recon.shape == (16, 3, 32, 32)
+    assert rel_l2(recon.detach().cpu(), r_ref) <= 2e-2 and rel_l2(mu.detach().cpu(), mu_ref) <= 5e-2
