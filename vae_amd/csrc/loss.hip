@@ -49,10 +49,14 @@ __global__ __launch_bounds__(256) void recon_loss_kernel(const float* __restrict
     const float4* r4 = (const float4*)recon;
     const float4* t4 = (const float4*)target;
     float4* g4 = (float4*)grad;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
-         i += (long)gridDim.x * blockDim.x) {
-        const float4 r = r4[i];
-        const float4 t = t4[i];
+    // two float4 pairs per trip: four 16-byte loads in flight per lane (a streaming kernel lives on bytes in flight)
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += 2 * stride) {
+        const long j = i + stride;
+        const bool two = j < n4;
+        const float4 r = r4[i], t = t4[i];
+        float4 r2 = r, t2 = t;
+        if (two) { r2 = r4[j]; t2 = t4[j]; }
         float4 g;
         float l0, l1, l2, l3;
         loss_elem<KIND>(r.x, t.x, gs, l0, g.x);
@@ -61,6 +65,14 @@ __global__ __launch_bounds__(256) void recon_loss_kernel(const float* __restrict
         loss_elem<KIND>(r.w, t.w, gs, l3, g.w);
         acc += (l0 + l1) + (l2 + l3);
         if (WRITE_GRAD) g4[i] = g;
+        if (two) {
+            loss_elem<KIND>(r2.x, t2.x, gs, l0, g.x);
+            loss_elem<KIND>(r2.y, t2.y, gs, l1, g.y);
+            loss_elem<KIND>(r2.z, t2.z, gs, l2, g.z);
+            loss_elem<KIND>(r2.w, t2.w, gs, l3, g.w);
+            acc += (l0 + l1) + (l2 + l3);
+            if (WRITE_GRAD) g4[j] = g;
+        }
     }
     // tail (n not a multiple of 4)
     if (blockIdx.x == 0) {
