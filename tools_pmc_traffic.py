@@ -18,7 +18,7 @@ import sys
 def bench_name(rocprof_name: str):
     """map a rocprofv3 kernel name onto the name the library's event profiler (and bench.py) uses"""
     n = rocprof_name
-    m = re.search(r"conv3_patch_tn_kernel<\d+, (\d+)>", n)
+    m = re.search(r"conv3_patch_tn_kernel<\d+, (\d+), \d+>", n)
     if m:
         return f"conv3_patch_tn_kernel<{m.group(1)}>"
     if "conv3_wgrad_patch_kernel" in n:
