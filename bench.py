@@ -169,10 +169,15 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch size")
     ap.add_argument("--side-stream", action="store_true",
                     help="run the weight-gradient kernels of the backward pass on a second stream")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo to rehearse ranks that share a GPU)")
+    ap.add_argument("--watchdog", type=int, default=0, help="dump every thread's stack and exit after this many seconds (0 = off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--torch-optimizer", action="store_true", help="torch.optim.AdamW + clip_grad_norm_ instead of the fused kernel")
     args = ap.parse_args()
+    if args.watchdog > 0:
+        import faulthandler
+        faulthandler.dump_traceback_later(args.watchdog, exit=True)
 
     import torch.distributed as dist
     from vae_amd import _lib
@@ -189,10 +194,15 @@ def main():
             raise SystemExit(f"--gpus {args.gpus} needs one process per GPU: launch with "
                              f"python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} "
                              f"--master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...")
+    if args.backend != "nccl":
+        local_rank %= torch.cuda.device_count()      # a rehearsal: several ranks may share one card
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
     _lib.load()
 
     conf = load_config(args.config, os.path.join(ROOT, "config"))
