@@ -237,6 +237,22 @@ int vae_bn_act_bwd_route(const void* gin, const void* y, const float* scale, con
                          const void* route, int n_img, int H, int W, int C, int pool, double p_drop,
                          const void* keep_mask, unsigned long long seed, unsigned step,
                          unsigned stream_id, unsigned rank, void* stream);
+/* ---- GroupNorm form of the double-conv block: nn.GroupNorm(8, C) + ReLU (+ nn.Dropout) (+ nn.MaxPool2d(2)),
+ *      vae/practice/vae_conv.py:20-36,50-59 and vae/practice/vae_original.py:58-74 ----------------------------
+ * y [n,H,W,C] bf16 (a conv output) -> out [n,H,W,C] or, with pool, [n,H/2,W/2,C].  Statistics are per image and
+ * group (biased variance, eps inside the square root), the same in train and eval mode.  mean_rstd
+ * [n][groups][2] f32 receives (mean, rstd) for the backward pass (may be null for inference).  C must be a
+ * multiple of 8*groups, at most 512.  Dropout flags as in vae_bn_act_fwd. */
+int vae_gn_act_fwd(const void* y, const float* gamma, const float* beta, void* out, float* mean_rstd,
+                   int n_img, int H, int W, int C, int groups, float eps, int pool, double p_drop,
+                   const void* keep_mask, unsigned long long seed, unsigned step, unsigned stream_id,
+                   unsigned rank, void* stream);
+/* its backward down to the conv output: gin = grad of the (pooled) block output, dy = grad of y;
+ * chan_partial [n][2][C] f32 scratch (per-image sums), dgamma_dbeta = [d gamma (C) | d beta (C)]. */
+int vae_gn_act_bwd(const void* gin, const void* y, const float* gamma, const float* beta,
+                   const float* mean_rstd, float* chan_partial, float* dgamma_dbeta, void* dy, int n_img,
+                   int H, int W, int C, int groups, int pool, double p_drop, const void* keep_mask,
+                   unsigned long long seed, unsigned step, unsigned stream_id, unsigned rank, void* stream);
 /* relu(bn1(.)) -> nn.Conv2d(64, Cout, 1) -> sigmoid, vae/models/vae.py:74,121-122.
  * y [n,H,W,64] bf16, w [Cout][64] f32, recon [n,Cout,H,W] f32 (NCHW, the module output). */
 int vae_head_fwd(const void* y, const float* scale, const float* shift, const float* w,

@@ -170,9 +170,47 @@ def case_train_steps(ref_vae, ref_train, name, cfg, n, seed, steps=3):
     print(f"wrote {path}: {os.path.getsize(path) / 1e6:.2f} MB")
 
 
+def case_double_conv_gn(name, cin, cout, n, size, p, seed):
+    """the reference's GroupNorm double-conv block itself (vae/practice/vae_conv.py:20-36) followed by the
+    MaxPool2d(2) of its encoder (:51): weights, input, train-mode output, pooled output, and the gradients of
+    sum(pooled * r) for a saved random r."""
+    import vae.practice.vae_conv as ref_gn
+    torch.manual_seed(seed)
+    blk = ref_gn.DoubleConv(cin, cout, p)
+    with torch.no_grad():
+        for k, v in blk.state_dict().items():      # away from the (1, 0) init of the affine
+            if ".1." in k or ".4." in k:
+                v.add_(0.3 * torch.randn_like(v))
+    blk.train()
+    masks = []
+    h = blk.double_conv[6].register_forward_hook(
+        lambda mod, inp, outp: masks.append(((outp != 0) | (inp[0] == 0)).to(torch.uint8)))
+    x = torch.randn(n, cin, size, size, requires_grad=True)
+    r = torch.randn(n, cout, size // 2, size // 2)
+    y = blk(x)
+    pooled = F.max_pool2d(y, 2)
+    (pooled * r).sum().backward()
+    h.remove()
+    out = {"cfg/cin": cin, "cfg/cout": cout, "cfg/n": n, "cfg/size": size, "cfg/p": p,
+           "x": x.detach().numpy().copy(), "r": r.numpy().copy(), "y": y.detach().numpy().copy(),
+           "pooled": pooled.detach().numpy().copy(), "grad/x": x.grad.numpy().copy(),
+           "mask/shape": np.array(masks[0].shape), "mask/bits": np.packbits(masks[0].numpy().reshape(-1))}
+    for k, v in blk.state_dict().items():
+        out[f"sd/{k}"] = v.detach().numpy().copy()
+    for k, v in blk.named_parameters():
+        out[f"grad/{k}"] = v.grad.numpy().copy()
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}: {os.path.getsize(path) / 1e6:.2f} MB")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref_vae, ref_train = import_reference()
+    if "--gn" in sys.argv:          # only the GroupNorm block fixtures (the others stay as committed)
+        case_double_conv_gn("gn_block", 8, 64, 3, 8, 0.0, 1350)
+        case_double_conv_gn("gn_block_dropout", 8, 64, 2, 8, 0.25, 1351)
+        return
     A = dict(in_channels=3, out_channels=3, latent_dims=128, p_dropout=0.0, image_size=32)
     Ad = dict(A, p_dropout=0.1)
     B = dict(in_channels=3, out_channels=3, latent_dims=256, p_dropout=0.0, image_size=64)

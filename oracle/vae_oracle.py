@@ -205,6 +205,32 @@ def double_conv(x, sd, prefix, train, p_dropout, mask, stats_out=None):
     return dropout(x, p_dropout, train, mask)
 
 
+GN_GROUPS = 8          # nn.GroupNorm(num_groups=8, ...), vae/practice/vae_conv.py:26,30
+GN_EPS = 1e-5          # nn.GroupNorm default
+
+
+def group_norm(x, gamma, beta, groups: int = GN_GROUPS, eps: float = GN_EPS):
+    """nn.GroupNorm forward (vae/practice/vae_conv.py:26,30; vae/practice/vae_original.py:64,68): per image
+    and group of C/groups channels, mean and BIASED variance over (C/groups, H, W); the same in train and
+    eval mode (no running statistics); then the per-channel affine."""
+    n, c, h, w = x.shape
+    xg = x.reshape(n, groups, (c // groups) * h * w)
+    mean = xg.mean(dim=2, keepdim=True)
+    var = ((xg - mean) ** 2).mean(dim=2, keepdim=True)
+    xhat = ((xg - mean) * torch.rsqrt(var + eps)).reshape(n, c, h, w)
+    return xhat * gamma[None, :, None, None] + beta[None, :, None, None]
+
+
+def double_conv_gn(x, sd, prefix, train, p_dropout, mask):
+    """The GroupNorm form of the double-conv block (vae/practice/vae_conv.py:20-36):
+    conv3x3, GroupNorm(8), ReLU, conv3x3, GroupNorm(8), ReLU, Dropout.  State names follow the
+    draft's nn.Sequential: ``{prefix}.double_conv.{0,1,3,4}.{weight,bias}``."""
+    for j in (0, 3):
+        x = F.conv2d(x, sd[f"{prefix}.double_conv.{j}.weight"], sd[f"{prefix}.double_conv.{j}.bias"], padding=1)
+        x = torch.relu(group_norm(x, sd[f"{prefix}.double_conv.{j + 1}.weight"], sd[f"{prefix}.double_conv.{j + 1}.bias"]))
+    return dropout(x, p_dropout, train, mask)
+
+
 def encode(x, sd, train=True, p_dropout=0.0, masks=None, stats_out=None):
     """VAEConv.encode (vae/models/vae.py:89-98) -> (mu, logvar)."""
     masks = masks or [None] * 4
