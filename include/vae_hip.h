@@ -248,9 +248,10 @@ int vae_gn_act_fwd(const void* y, const float* gamma, const float* beta, void* o
                    const void* keep_mask, unsigned long long seed, unsigned step, unsigned stream_id,
                    unsigned rank, void* stream);
 /* its backward down to the conv output: gin = grad of the (pooled) block output, dy = grad of y;
- * chan_partial [n][2][C] f32 scratch (per-image sums), dgamma_dbeta = [d gamma (C) | d beta (C)]. */
+ * chan_partial [n][3][C] f32 scratch (per-image sums), sums = [d gamma (C) | d beta (C) | sum of dy per
+ * channel (C), i.e. the bias gradient of the conv that produced y]. */
 int vae_gn_act_bwd(const void* gin, const void* y, const float* gamma, const float* beta,
-                   const float* mean_rstd, float* chan_partial, float* dgamma_dbeta, void* dy, int n_img,
+                   const float* mean_rstd, float* chan_partial, float* sums, void* dy, int n_img,
                    int H, int W, int C, int groups, int pool, double p_drop, const void* keep_mask,
                    unsigned long long seed, unsigned step, unsigned stream_id, unsigned rank, void* stream);
 /* relu(bn1(.)) -> nn.Conv2d(64, Cout, 1) -> sigmoid, vae/models/vae.py:74,121-122.

@@ -73,14 +73,16 @@ def test_gn_act_fwd_bwd(L, n, H, W, C, pool, p, inject):
     assert rel_l2(mr[:, :, 0].cpu(), yg.mean(2)) <= 1e-5
     assert rel_l2(mr[:, :, 1].cpu(), torch.rsqrt(yg.var(2, unbiased=False) + 1e-5)) <= 1e-5
     check_bf16(from_nhwc(out), out_ref.detach(), "gn_act fwd")
-    part = torch.full((n, 2, C), float("nan"), device=DEV)
-    sums = torch.full((2 * C,), float("nan"), device=DEV)
+    part = torch.full((n, 3, C), float("nan"), device=DEV)
+    sums = torch.full((3 * C,), float("nan"), device=DEV)
     dy = torch.full((n, H, W, C), float("nan"), device=DEV, dtype=torch.bfloat16)
     L.call("vae_gn_act_bwd", L.ptr(nhwc(gin)), L.ptr(yd), L.ptr(gd), L.ptr(bd), L.ptr(mr), L.ptr(part), L.ptr(sums), L.ptr(dy),
            n, H, W, C, 8, pool, p, L.ptr(md), seed, step, stream_id, rank, L.current_stream())
     assert rel_l2(sums[:C].cpu(), gr.grad) <= 2e-5
-    assert rel_l2(sums[C:].cpu(), br.grad) <= 2e-5
+    assert rel_l2(sums[C:2 * C].cpu(), br.grad) <= 2e-5
     check_bf16(from_nhwc(dy), yr.grad, "gn_act bwd")
+    # third row: per-channel sum of dy (what the bias of the conv in front receives)
+    assert (sums[2 * C:].cpu() - yr.grad.sum((0, 2, 3))).abs().max() <= 1e-4 * yr.grad.abs().sum((0, 2, 3)).max() + 1e-6
 
 
 def test_gn_rejects_bad_geometry(L):
@@ -92,3 +94,85 @@ def test_gn_rejects_bad_geometry(L):
     with pytest.raises(RuntimeError, match="pooling needs even"):
         L.call("vae_gn_act_fwd", L.ptr(t), L.ptr(f), L.ptr(f), L.ptr(t), None, 1, 3, 4, 64, 8, 1e-5, 1, 0.0, None, 0, 0, 0, 0,
                L.current_stream())
+
+
+# ------------------------------------------------------------------ the whole block against the reference's fixtures
+def _load_block(name):
+    import os
+    import numpy as np
+    from golden_util import GOLDEN
+    from vae_amd.variants import DoubleConvGN
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    blk = DoubleConvGN(int(z["cfg/cin"]), int(z["cfg/cout"]), float(z["cfg/p"]))
+    blk.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")})   # the reference's own names
+    shp = tuple(int(v) for v in z["mask/shape"])
+    mask = torch.from_numpy(np.unpackbits(z["mask/bits"])[: int(np.prod(shp))].reshape(shp).copy())
+    return z, blk.to(DEV).train(), mask
+
+
+@pytest.mark.parametrize("name", ["gn_block", "gn_block_dropout"])
+def test_double_conv_gn_block_against_the_reference_fixture(name):
+    """DoubleConvGN (conv, GroupNorm, ReLU, conv, GroupNorm, ReLU, dropout) + the encoder's max-pool, on the
+    outputs and gradients of the reference's own draft block (bf16 tolerances; dropout mask injected)"""
+    z, blk, mask = _load_block(name)
+    x = torch.from_numpy(z["x"]).to(DEV)
+    km = mask.permute(0, 2, 3, 1).contiguous().to(DEV) if float(z["cfg/p"]) > 0 else None
+    y = blk(x, keep_mask=km)
+    assert y.shape == tuple(z["y"].shape) and y.dtype == torch.float32
+    assert rel_l2(y.detach().cpu(), z["y"]) <= 2e-2
+    pooled = blk.forward_nhwc(x, pool=True, keep_mask=km)
+    assert rel_l2(pooled.detach().float().cpu().permute(0, 3, 1, 2), z["pooled"]) <= 2e-2
+    r = torch.from_numpy(z["r"]).permute(0, 2, 3, 1).contiguous().to(DEV)
+    (pooled.float() * r).sum().backward()
+    # a few hundred pixels: every bf16-flipped ReLU / max-pool route shows in a tensor's gradient, so the bound per
+    # tensor is loose and the direction over all parameters is the sharp check
+    dot = ng = nr = 0.0
+    for k, prm in blk.named_parameters():
+        got, ref = prm.grad.cpu().flatten().double(), torch.from_numpy(z["grad/" + k]).flatten().double()
+        assert rel_l2(got, ref) <= 0.12, (k, rel_l2(got, ref))
+        dot, ng, nr = dot + float(got @ ref), ng + float(got @ got), nr + float(ref @ ref)
+    assert dot / (ng * nr) ** 0.5 >= 0.995
+
+
+def test_double_conv_gn_chain_against_the_oracle():
+    """two blocks in the kernels' layout (8 -> 64 pooled -> 128), Philox dropout: outputs and all gradients,
+    input gradient of the second block included, against the oracle"""
+    from vae_amd.variants import DoubleConvGN
+    torch.manual_seed(3)
+    b0, b1 = DoubleConvGN(3, 64, 0.1).to(DEV).train(), DoubleConvGN(64, 128, 0.1).to(DEV).train()
+    for i, b in enumerate((b0, b1)):
+        b.rng_seed, b.rng_step, b.stream_id, b.rank = 21, 4, i, 1
+        with torch.no_grad():
+            for k, v in b.named_parameters():
+                if ".1." in k or ".4." in k:
+                    v.add_(0.2 * torch.randn_like(v))
+    n, S = 6, 16
+    x = torch.rand(n, 3, S, S, generator=torch.Generator().manual_seed(1))
+    h = b0.forward_nhwc(x.to(DEV), pool=True)
+    out = b1.forward_nhwc(h, pool=True)
+    assert b0.rng_step == 5 and out.shape == (n, S // 4, S // 4, 128)
+    # positive upstream gradient: with a random-sign one the sums over pixels cancel and every bf16-flipped route
+    # shows up many times larger in the relative error
+    r = torch.rand(out.shape, generator=torch.Generator().manual_seed(2)) + 0.5
+    (out.float() * r.to(DEV)).sum().backward()
+    # oracle
+    sd = {}
+    for i, b in enumerate((b0, b1)):
+        for k, v in b.state_dict().items():
+            sd[f"b{i}.{k}"] = v.detach().cpu().clone().requires_grad_(True)
+    m0 = torch.from_numpy(O.philox_keep_mask(n * S * S * 64, 0.1, 21, 0, 4, 1)).view(n, S, S, 64).permute(0, 3, 1, 2)
+    m1 = torch.from_numpy(O.philox_keep_mask(n * (S // 2) ** 2 * 128, 0.1, 21, 1, 4, 1)).view(n, S // 2, S // 2, 128).permute(0, 3, 1, 2)
+    h_ref = F.max_pool2d(O.double_conv_gn(x, sd, "b0", True, 0.1, m0), 2)
+    o_ref = F.max_pool2d(O.double_conv_gn(h_ref, sd, "b1", True, 0.1, m1), 2)
+    assert rel_l2(out.detach().float().cpu().permute(0, 3, 1, 2), o_ref.detach()) <= 3e-2
+    (o_ref * r.permute(0, 3, 1, 2)).sum().backward()
+    dot = ng = nr = 0.0
+    errs = {}
+    for i, b in enumerate((b0, b1)):
+        for k, prm in b.named_parameters():
+            got, ref = prm.grad.cpu().flatten().double(), sd[f"b{i}.{k}"].grad.flatten().double()
+            errs[f"b{i}.{k}"] = round(rel_l2(got, ref), 4)
+            dot, ng, nr = dot + float(got @ ref), ng + float(got @ got), nr + float(ref @ ref)
+    print(errs, dot / (ng * nr) ** 0.5)
+    assert max(errs.values()) <= 0.08, errs          # four bf16 conv + GroupNorm stages deep, 6 images
+    assert dot / (ng * nr) ** 0.5 >= 0.998

@@ -205,7 +205,7 @@ __global__ __launch_bounds__(GN_T) void gn_act_bwd_kernel(const bf16_t* __restri
         float s = 0.f;
         for (int t = c >> 3; t < GN_T; t += cgs) s += red[row][t][c & 7];
         chs[row][c] = s;
-        chan_partial[(img * 2 + row) * g.C + c] = s;     // [d gamma | d beta] of this image
+        chan_partial[(img * 3 + row) * g.C + c] = s;     // [d gamma | d beta] of this image
     }
     __syncthreads();
     if (threadIdx.x < g.G) {
@@ -221,7 +221,10 @@ __global__ __launch_bounds__(GN_T) void gn_act_bwd_kernel(const bf16_t* __restri
     __syncthreads();
     const float cA = coef[grp][0], cB = coef[grp][1];
 
-    // pass B: dy
+    // pass B: dy, and its per-channel sum (the bias gradient of the conv that produced y)
+    float a_dy[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a_dy[i] = 0.f;
     for (int pos = threadIdx.x >> cshift; pos < npos; pos += GN_T >> cshift) {
         long idx[4], gidx;
         locate(pos, idx, gidx);
@@ -231,9 +234,20 @@ __global__ __launch_bounds__(GN_T) void gn_act_bwd_kernel(const bf16_t* __restri
         for (int k = 0; k < K; ++k) {
             float o[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) o[i] = rstd * (gm[i] * gg[k][i] - cB - xh[k][i] * cA);
+            for (int i = 0; i < 8; ++i) {
+                o[i] = rstd * (gm[i] * gg[k][i] - cB - xh[k][i] * cA);
+                a_dy[i] += o[i];
+            }
             store8(dy + idx[k], o);
         }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[0][threadIdx.x][i] = a_dy[i];      // (every read of red above is behind two barriers)
+    __syncthreads();
+    for (int c = threadIdx.x; c < g.C; c += GN_T) {
+        float s = 0.f;
+        for (int t = c >> 3; t < GN_T; t += cgs) s += red[0][t][c & 7];
+        chan_partial[(img * 3 + 2) * g.C + c] = s;
     }
 }
 
@@ -267,10 +281,10 @@ extern "C" int vae_gn_act_fwd(const void* y, const float* gamma, const float* be
 }
 
 extern "C" int vae_gn_act_bwd(const void* gin, const void* y, const float* gamma, const float* beta, const float* mean_rstd,
-                              float* chan_partial, float* dgamma_dbeta, void* dy, int n_img, int H, int W, int C, int groups,
+                              float* chan_partial, float* sums, void* dy, int n_img, int H, int W, int C, int groups,
                               int pool, double p_drop, const void* keep_mask, unsigned long long seed, unsigned step,
                               unsigned stream_id, unsigned rank, void* stream) {
-    VAE_CHECK(gin && y && gamma && beta && mean_rstd && chan_partial && dgamma_dbeta && dy, "vae_gn_act_bwd: null pointer");
+    VAE_CHECK(gin && y && gamma && beta && mean_rstd && chan_partial && sums && dy, "vae_gn_act_bwd: null pointer");
     if (int e = gn_check("vae_gn_act_bwd", n_img, H, W, C, groups, pool)) return e;
     VAE_CHECK(p_drop >= 0.0 && p_drop < 1.0, "vae_gn_act_bwd: p_drop=%f out of [0,1)", p_drop);
     const GnGeom g = {n_img, H, W, C, groups, 0.f};
@@ -283,6 +297,6 @@ extern "C" int vae_gn_act_bwd(const void* gin, const void* y, const float* gamma
         else hipLaunchKernelGGL(gn_act_bwd_kernel<false>, dim3(n_img), dim3(GN_T), 0, s, (const bf16_t*)gin, (const bf16_t*)y, gamma, beta, mean_rstd, chan_partial, (bf16_t*)dy, g, d);
         VAE_LAUNCH_CHECK("gn_act_bwd_kernel");
     }
-    // [d gamma | d beta] = the per-image rows folded over the images (fixed order)
-    return vae_sum_partials(chan_partial, n_img, 2 * C, dgamma_dbeta, 1.0f, stream);
+    // [d gamma | d beta | d bias] = the per-image rows folded over the images (fixed order)
+    return vae_sum_partials(chan_partial, n_img, 3 * C, sums, 1.0f, stream);
 }
