@@ -88,6 +88,22 @@ def main():
         "vae_bn_act_bwd_route", gp.data_ptr(), y.data_ptr(), sc.data_ptr(), sh.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
         partp.data_ptr(), sums.data_ptr(), dy.data_ptr(), route.data_ptr(), N, H, H, C, 1, 0.1, None, 1337, 0, 0, 0, s()))
 
+    # ---- GroupNorm(8) + ReLU (+ dropout + pool): one workgroup per image; algorithmic bytes count y ONCE per pass
+    # (the second read of an image comes from L2), gin and the output once
+    mr = torch.empty(N, 8, 2, device=dev)
+    add("gn_act_fwd", 4.0 * e, lambda: L.call("vae_gn_act_fwd", y.data_ptr(), sc.data_ptr(), sh.data_ptr(), out.data_ptr(),
+                                              mr.data_ptr(), N, H, H, C, 8, 1e-5, 0, 0.0, None, 0, 0, 0, 0, s()))
+    add("gn_act_fwd<pool, dropout 0.1>", 2.0 * e * 1.25, lambda: L.call(
+        "vae_gn_act_fwd", y.data_ptr(), sc.data_ptr(), sh.data_ptr(), outp.data_ptr(), mr.data_ptr(), N, H, H, C, 8, 1e-5, 1,
+        0.1, None, 1337, 0, 0, 0, s()))
+    cpart, csums = torch.empty(N, 3, C, device=dev), torch.empty(3 * C, device=dev)
+    add("gn_act_bwd", 2.0 * e * 3, lambda: L.call(
+        "vae_gn_act_bwd", g.data_ptr(), y.data_ptr(), sc.data_ptr(), sh.data_ptr(), mr.data_ptr(), cpart.data_ptr(),
+        csums.data_ptr(), dy.data_ptr(), N, H, H, C, 8, 0, 0.0, None, 0, 0, 0, 0, s()))
+    add("gn_act_bwd<pool, dropout 0.1>", 2.0 * e * 2.25, lambda: L.call(
+        "vae_gn_act_bwd", gp.data_ptr(), y.data_ptr(), sc.data_ptr(), sh.data_ptr(), mr.data_ptr(), cpart.data_ptr(),
+        csums.data_ptr(), dy.data_ptr(), N, H, H, C, 8, 1, 0.1, None, 1337, 0, 0, 0, s()))
+
     # ---- bn1 + ReLU + 1x1 head + sigmoid: reads the 64-channel tensor, writes 3 fp32 planes
     w, b = torch.randn(3, 64, device=dev) * 0.1, torch.zeros(3, device=dev)
     rec = torch.empty(N, 3, H, H, device=dev)

@@ -37,17 +37,20 @@ __device__ __forceinline__ void gn_image_stats(const bf16_t* __restrict__ yimg, 
 #pragma unroll
         for (int i = 0; i < 8; ++i) { s += v[i]; q += v[i] * v[i]; }
     }
-    red[threadIdx.x] = s;
-    red[GN_T + threadIdx.x] = q;
+    // fold inside the wave first (a fixed shuffle tree): lanes that share a channel group sit cgs apart, and the
+    // cpg channel groups of one GroupNorm group are neighbours
+    const int cgs = g.C >> 3, cpg = cgs / g.G;
+    for (int o = 32; o >= cgs; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+    for (int o = cpg >> 1; o >= 1; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < cgs && (lane & (cpg - 1)) == 0) {
+        red[wave * g.G + lane / cpg] = s;
+        red[GN_T + wave * g.G + lane / cpg] = q;
+    }
     __syncthreads();
     if (threadIdx.x < g.G) {
-        // the threads of group gi: channel group (t & (cgs-1)) in [gi*cpg, (gi+1)*cpg), folded in a fixed order
-        const int cgs = g.C >> 3, cpg = cgs / g.G;
         double S = 0.0, Q = 0.0;
-        for (int t = 0; t < GN_T; ++t) {
-            const int cg = t & (cgs - 1);
-            if (cg / cpg == (int)threadIdx.x) { S += (double)red[t]; Q += (double)red[GN_T + t]; }
-        }
+        for (int w = 0; w < GN_T / 64; ++w) { S += (double)red[w * g.G + threadIdx.x]; Q += (double)red[GN_T + w * g.G + threadIdx.x]; }
         const double m = (double)hw * (g.C / g.G);
         const double mean = S / m;
         double var = Q / m - mean * mean;
