@@ -176,3 +176,30 @@ def test_double_conv_gn_chain_against_the_oracle():
     print(errs, dot / (ng * nr) ** 0.5)
     assert max(errs.values()) <= 0.08, errs          # four bf16 conv + GroupNorm stages deep, 6 images
     assert dot / (ng * nr) ** 0.5 >= 0.998
+
+
+@pytest.mark.parametrize("cin,cout,n,S", [(192, 64, 4, 16), (384, 128, 3, 8), (128, 64, 2, 32)])
+def test_refine_block_channel_counts_against_the_oracle(cin, cout, n, S):
+    """the channel counts of the drafts' U-Net refine blocks, DoubleConv(64+128, 64), (128+256, 128), (64+64, 64)
+    (vae/practice/vae_original.py:111-117): the concatenated input is not a power of two wide; forward, input
+    gradient and weight gradients on the same conv kernels"""
+    from vae_amd.variants import DoubleConvGN
+    torch.manual_seed(cin)
+    blk = DoubleConvGN(cin, cout, 0.0).to(DEV).train()
+    g = torch.Generator().manual_seed(cin + S)
+    up, skip = torch.randn(n, cin - cout, S, S, generator=g), torch.randn(n, cout, S, S, generator=g)
+    x = torch.cat([up, skip], dim=1)                       # torch.cat([up, d], dim=1) of the draft's forward
+    xd = x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV).requires_grad_(True)
+    out = blk.forward_nhwc(xd)
+    r = torch.rand(n, cout, S, S, generator=g) + 0.5
+    (out.float() * r.permute(0, 2, 3, 1).to(DEV)).sum().backward()
+    sd = {"b." + k: v.detach().cpu().clone().requires_grad_(True) for k, v in blk.state_dict().items()}
+    xr = x.to(torch.bfloat16).float().requires_grad_(True)
+    o_ref = O.double_conv_gn(xr, sd, "b", True, 0.0, None)
+    assert rel_l2(out.detach().float().cpu().permute(0, 3, 1, 2), o_ref.detach()) <= 2e-2
+    (o_ref * r).sum().backward()
+    # about 0.3 % of the ReLU decisions behind a bf16 conv output flip, each moving one gradient element by its full size:
+    # ~10 % in the L2 norm of every gradient below the last GroupNorm whatever the channel count (a layout error gives ~140 %)
+    assert rel_l2(xd.grad.float().cpu().permute(0, 3, 1, 2), xr.grad) <= 0.15
+    for k, prm in blk.named_parameters():
+        assert rel_l2(prm.grad.cpu(), sd["b." + k].grad) <= (0.01 if ".4." in k else 0.15), k

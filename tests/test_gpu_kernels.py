@@ -169,7 +169,11 @@ def check_bf16(got, ref, what):
                                          (8, 64, 64, 64, 64), (40, 32, 32, 128, 256),
                                          # enough 64-channel work for the 256-pixel tiles: four 8x8 images, one 16x16 image,
                                          # 8 rows of 32, 4 rows of 64 per tile; two channel chunks
-                                         (2048, 8, 8, 64, 64), (512, 16, 16, 128, 64), (128, 32, 32, 64, 64), (32, 64, 64, 64, 64)])
+                                         (2048, 8, 8, 64, 64), (512, 16, 16, 128, 64), (128, 32, 32, 64, 64), (32, 64, 64, 64, 64),
+                                         # channel counts that are multiples of 64 but not powers of two (concatenated
+                                         # skip inputs), on the small-problem tiles and on the patch kernel
+                                         (4, 16, 16, 192, 64), (4, 16, 16, 64, 192), (3, 8, 8, 384, 128), (3, 8, 8, 128, 384),
+                                         (300, 16, 16, 192, 64), (300, 16, 16, 64, 192)])
 def test_conv3x3_fwd_dgrad(L, n, H, W, Ci, Co):
     g = torch.Generator().manual_seed(n + H + Ci)
     x = bf(torch.randn(n, Ci, H, W, generator=g))
