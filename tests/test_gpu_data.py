@@ -102,3 +102,32 @@ def test_checkpoint_and_sampling_through_the_model(tmp_path):
     assert s1.shape == (6, 3, 16, 16) and torch.equal(s1, s2)
     assert float(s1.min()) > 0 and float(s1.max()) < 1
     data.save_image_grid(s1, str(tmp_path / "samples.ppm"), nrow=3)
+
+
+def test_fit_runs_the_reference_epoch_loop(tmp_path):
+    """train pass, eval pass, best-model checkpoint on improvement, one record per epoch (train.py:316-373)"""
+    from vae_amd.data import DeviceFeed, load_checkpoint, split_indices
+    from vae_amd.optim import FlatAdamW
+    from vae_amd.train import Config, fit
+    from vae_amd.vae import VAEConv
+    torch.manual_seed(0)
+    imgs = torch.randint(0, 256, (200, 32, 32, 3), dtype=torch.uint8, device="cuda")
+    tr, va = split_indices(200, 0.9, torch.Generator().manual_seed(1))
+    m = VAEConv(3, 3, 64, 0.1, 32).cuda()
+    conf = Config(kl_weight=1.0, percep_weight=0.0, recon_loss="l1", lr=1e-3, n_epochs=3, save_model=True)
+    path = str(tmp_path / "best-model.pth")
+    seen = []
+    hist = fit(m, FlatAdamW(m, lr=1e-3), conf, DeviceFeed(imgs, 32, tr, shuffle=True), DeviceFeed(imgs, 32, va), log=seen.append,
+               checkpoint_path=path)
+    assert hist == seen and [r["epoch"] for r in hist] == [1, 2, 3]
+    assert all(torch.isfinite(torch.tensor([r["train/loss"], r["val/loss"]])).all() for r in hist)
+    assert hist[-1]["train/loss"] < hist[0]["train/loss"]
+    assert not m.training                                    # the loop leaves the model in eval mode, as the reference does
+    m2 = VAEConv(3, 3, 64, 0.1, 32).cuda()
+    load_checkpoint(m2, path)                                 # the checkpoint is a plain reference-format state_dict
+    assert set(m2.state_dict()) == set(m.state_dict())
+    # the autograd path gives the same kind of record
+    hist2 = fit(m, torch.optim.AdamW(m.parameters(), lr=1e-3), Config(kl_weight=1.0, percep_weight=0.0, recon_loss="l1", lr=1e-3,
+                                                                    n_epochs=1, save_model=False),
+                DeviceFeed(imgs, 32, tr), DeviceFeed(imgs, 32, va), fused=False)
+    assert len(hist2) == 1 and hist2[0]["train/loss"] < hist[0]["train/loss"]

@@ -214,3 +214,44 @@ class FusedStep:
             torch.nn.utils.clip_grad_norm_(m.parameters(), max_norm=self.max_norm)
             self.optimizer.step()
         return out3[0]
+
+
+# ---------------------------------------------------------------------- epoch loop
+def fit(model, optimizer, config, train_feed, val_feed, log=None, checkpoint_path="best-model.pth", reducer=None,
+        fused=True):
+    """The reference's epoch loop (train.py:316-373) around the train / val steps above: per epoch a training
+    pass (``model.train()``), a validation pass (``model.eval()``, no gradients, eps still sampled), the epoch
+    losses as the mean of the per-batch losses, and -- when ``config.save_model`` -- ``best-model.pth`` rewritten
+    whenever the validation loss improves (train.py:360-367).  ``log`` receives what the reference hands to
+    ``wandb.log`` (train.py:369-373); the list of those records is returned.
+
+    ``train_feed`` / ``val_feed`` are iterables of device batches (``vae_amd.data.DeviceFeed``, or a DataLoader
+    whose batches are moved with ``.to(device)``; ``(inputs, label)`` pairs are accepted).  The per-batch losses
+    stay on the device and are read once per epoch (the reference's ``loss.item()`` every step stalls the stream;
+    the numbers are the same).  ``fused=True`` runs ``FusedStep`` (requires ``FlatAdamW``); otherwise the
+    autograd ``train_step``."""
+    from .data import save_checkpoint
+    step = FusedStep(model, optimizer, config, reducer) if fused else None
+    best_val_loss = float("inf")
+    history = []
+
+    def batches(feed):
+        for b in feed:
+            yield b[0] if isinstance(b, (tuple, list)) else b
+
+    for epoch in range(1, int(config.n_epochs) + 1):
+        model.train()
+        losses = [(step(x) if fused else train_step(model, optimizer, x, config)).clone() for x in batches(train_feed)]
+        train_epoch_loss = float(torch.stack(losses).sum()) / max(len(losses), 1)
+        model.eval()
+        with torch.no_grad():
+            losses = [val_step(model, x, config).clone() for x in batches(val_feed)]
+        val_epoch_loss = float(torch.stack(losses).sum()) / max(len(losses), 1) if losses else float("nan")
+        if getattr(config, "save_model", False) and val_epoch_loss < best_val_loss:
+            best_val_loss = val_epoch_loss
+            save_checkpoint(model, checkpoint_path)
+        rec = {"epoch": epoch, "train/loss": train_epoch_loss, "val/loss": val_epoch_loss}
+        history.append(rec)
+        if log is not None:
+            log(rec)
+    return history
