@@ -339,7 +339,16 @@ __global__ __launch_bounds__(256) void multi_pack_kernel(const PackJobs jobs) {
     const PackJob& jb = jobs.j[blockIdx.y];
     const int step = jb.vec8 ? 8 : 1;
     const int items = jb.n / step;
-    for (int it = blockIdx.x * blockDim.x + threadIdx.x; it < items; it += gridDim.x * blockDim.x) {
+    // Workgroups go round-robin over the 8 XCDs, each with its own L2, and neighbouring destination runs gather from
+    // the same source lines: give every XCD one contiguous eighth of the job (gridDim.x is a multiple of 8, or < 8)
+    int begin = blockIdx.x * blockDim.x, end = items, stride = gridDim.x * blockDim.x;
+    if ((gridDim.x & 7) == 0) {
+        const int per = (items + 7) >> 3, xcd = blockIdx.x & 7;
+        begin = xcd * per + (blockIdx.x >> 3) * blockDim.x;
+        end = min(items, (xcd + 1) * per);
+        stride = (gridDim.x >> 3) * blockDim.x;
+    }
+    for (int it = begin + threadIdx.x; it < end; it += stride) {
         const unsigned e = (unsigned)it * step;
         const unsigned i3 = e % (unsigned)jb.d3;
         unsigned t = e / (unsigned)jb.d3;
@@ -606,6 +615,7 @@ extern "C" int vae_multi_pack(const vae_pack_job* jobs, int njobs, void* stream)
     }
     int gx = (max_items + 255) / 256;
     if (gx > 128) gx = 128;
+    if (gx > 8) gx &= ~7;          // whole rounds of the 8 XCDs (the kernel then keeps each XCD on its own part of a job)
     ProfScope prof("multi_pack_kernel", 0.0, bytes, (hipStream_t)stream);
     hipLaunchKernelGGL(multi_pack_kernel, dim3(gx, njobs), dim3(256), 0, (hipStream_t)stream, pj);
     VAE_LAUNCH_CHECK("multi_pack_kernel");
