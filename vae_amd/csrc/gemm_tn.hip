@@ -95,7 +95,12 @@ __device__ __forceinline__ void wait_vm_groups(int groups) {
 
 // NST-deep ring of LDS stages: the copies of K-step ks + NST - 1 are issued while K-step ks computes, so a
 // tile has NST - 1 K-steps of compute to arrive (one K-step is shorter than an L2 round trip).
-template <int BM, int BN, int BK, int WAVES_M, int AMODE, int EPI, int NST>
+//
+// PERSIST (launches of one or two K-steps, no split-K): a workgroup walks the row tiles blockIdx.x, + gridDim.x, ...
+// and requests the NEXT tile's operands before it starts the epilogue of the current one.  Such a launch is little
+// more than a load phase and a store phase per tile; walked this way the two overlap inside a workgroup instead of
+// only between the two or three workgroups that fit a CU.
+template <int BM, int BN, int BK, int WAVES_M, int AMODE, int EPI, int NST, bool PERSIST = false>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
     constexpr int WAVES_N = 4 / WAVES_M;
     constexpr int TM = BM / WAVES_M, TN = BN / WAVES_N;
@@ -112,11 +117,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
     static_assert((NST - 2) * (A_INSTR + B_INSTR) <= 63, "vmcnt is a 6-bit counter");
 
     __shared__ __attribute__((aligned(16))) unsigned char smem[NST * STAGE];
+    __shared__ float red_persist[PERSIST ? 2 * WAVES_M * BN : 1];     // statistics scratch that does not alias the stages
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: addresses and branches built on it stay scalar
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    int m0 = blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
 
     // ---- per-lane staging state ------------------------------------------------------
     // Tiles are fetched with buffer_load ... lds: a 32-bit byte offset per lane against a buffer
@@ -129,11 +136,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
     unsigned a_off[A_INSTR];   // byte offset of this lane's 16-byte chunk at K = 0 (OOB: row >= M)
     int a_hw[A_INSTR];
     int a_chunk[A_INSTR];
+    auto setup_a = [&](int mbase) {
 #pragma unroll
     for (int i = 0; i < A_INSTR; ++i) {
         const int row = (wave + 4 * i) * RPI + lane / CH;
         const int chunk = (lane % CH) ^ ((row >> SW) & (CH - 1));
-        const int m = m0 + row;
+        const int m = mbase + row;
         a_hw[i] = 0;
         a_chunk[i] = chunk;
         int w, h, img;
@@ -155,6 +163,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
             if (m >= p.M) a_hw[i] = 0x7FFF7FFF;     // fails every bounds test below
         }
     }
+    };
+    setup_a(m0);
     unsigned b_off[B_INSTR];
 #pragma unroll
     for (int i = 0; i < B_INSTR; ++i) {
@@ -207,10 +217,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
     };
 
     f32x4 acc[FM][FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // the bias row is requested before the first tile: a load at the top of the epilogue would expose a memory round
     // trip in every workgroup, and short-K launches are little more than prologue + epilogue
@@ -229,8 +235,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
     const int ks0 = p.ksteps > 0 ? (int)blockIdx.z * p.ksteps : 0;
     const int nk = p.ksteps > 0 ? min(p.ksteps, p.K / BK - ks0) : p.K / BK;
 #pragma unroll
-    for (int q = 0; q < NST - 1; ++q)
+    for (int q = 0; q < (PERSIST ? NST : NST - 1); ++q)     // PERSIST: nk <= NST, every K-step of a tile has its own stage
         if (q < nk) stage(q, ks0 + q);
+    const int ntiles = (p.M + BM - 1) / BM;
+    for (int tile = blockIdx.x;; tile += gridDim.x) {
+    m0 = tile * BM;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     int slot = 0;                     // ring slot of K-step ks
     for (int ks = 0; ks < nk; ++ks) {
         wait_vm_groups<A_INSTR + B_INSTR>(min(NST - 2, nk - 1 - ks));   // everything up to K-step ks has landed
@@ -254,7 +267,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
                 wb[kk][j] = *(const bf16x8*)(bbase + row * ROWB + ((chunk ^ ((row >> SW) & (CH - 1))) << 4));
             }
         }
-        if (ks + NST - 1 < nk) stage(slot == 0 ? NST - 1 : slot - 1, ks0 + ks + NST - 1);   // the slot read in K-step ks - 1
+        if (!PERSIST && ks + NST - 1 < nk) stage(slot == 0 ? NST - 1 : slot - 1, ks0 + ks + NST - 1);   // the slot read in K-step ks - 1
         slot = slot + 1 == NST ? 0 : slot + 1;
 #pragma unroll
         for (int kk = 0; kk < BK / 32; ++kk)
@@ -263,6 +276,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
 #pragma unroll
                 for (int j = 0; j < FN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[kk][j], xa[kk][i], acc[i][j], 0, 0, 0);
+    }
+
+    if (PERSIST && tile + (int)gridDim.x < ntiles) {
+        barrier_keep_copies();            // every wave has its last fragments: the stages are free
+        setup_a(m0 + (int)gridDim.x * BM);
+#pragma unroll
+        for (int q = 0; q < NST; ++q)
+            if (q < nk) stage(q, ks0 + q);
     }
 
     // ---- epilogue ----------------------------------------------------------------------
@@ -317,8 +338,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
     }
 
     if (want_stats) {
-        __syncthreads();   // every wave is done reading the staging buffers
-        float* red = (float*)smem;   // [2][WAVES_M][BN]
+        // every wave is done reading the staging buffers (PERSIST: own scratch, and no fence that would drain the
+        // next tile's copies; the barrier keeps the previous tile's readers of the scratch apart from the writers)
+        if (PERSIST) barrier_keep_copies(); else __syncthreads();
+        float* red = PERSIST ? red_persist : (float*)smem;   // [2][WAVES_M][BN]
         // all 16-lane sums first (independent DPP chains), then one predicated block of LDS stores
 #pragma unroll
         for (int j = 0; j < FN; ++j)
@@ -337,15 +360,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmTN p) {
                     red[(WAVES_M + wm) * BN + c] = ssq[j][r];
                 }
         }
-        __syncthreads();
+        if (PERSIST) barrier_keep_copies(); else __syncthreads();
         if (tid < BN && n0 + tid < p.N) {
             float s = 0.f, q = 0.f;
 #pragma unroll
             for (int w = 0; w < WAVES_M; ++w) { s += red[w * BN + tid]; q += red[(WAVES_M + w) * BN + tid]; }
-            p.stat_sum[(long)blockIdx.x * p.N + n0 + tid] = s;
-            p.stat_sq[(long)blockIdx.x * p.N + n0 + tid] = q;
+            p.stat_sum[(long)tile * p.N + n0 + tid] = s;
+            p.stat_sq[(long)tile * p.N + n0 + tid] = q;
         }
     }
+    if (!PERSIST || tile + (int)gridDim.x >= ntiles) break;
+    }   // tile loop
 }
 
 template <int BM, int BN, int BK, int WAVES_M, int AMODE, int EPI>
@@ -364,7 +389,12 @@ static int launch_one(const GemmTN& p, hipStream_t s) {
     // two stages leave room for a third (or fifth) workgroup per CU, and these launches live on how many
     // workgroups overlap their load, compute and store phases
     const int nk = p.ksteps > 0 ? p.ksteps : p.K / BK;
-    if (NST != 2 && nk <= 2)
+    constexpr int PER_CU = 2 * STAGE_BYTES + 4096 <= 160 * 1024 / 3 ? 3 : 2;     // resident workgroups with two stages
+    if (p.ksteps <= 0 && nk <= 2 && (long)grid.x * grid.y > 256 * PER_CU) {
+        // more tiles than the chip holds at once: resident workgroups walk them (see PERSIST)
+        grid.x = (256 * PER_CU + grid.y - 1) / grid.y;
+        hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, BK, WAVES_M, AMODE, EPI, 2, true>), grid, dim3(256), 0, s, p);
+    } else if (NST != 2 && nk <= 2)
         hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, BK, WAVES_M, AMODE, EPI, 2>), grid, dim3(256), 0, s, p);
     else if (NST_DEEP != NST && (long)grid.x * grid.y * grid.z <= 256 && p.K / BK >= 8)
         hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, BK, WAVES_M, AMODE, EPI, NST_DEEP>), grid, dim3(256), 0, s, p);
