@@ -168,3 +168,30 @@ def test_single_channel_input_against_the_oracle():
         r_ref, mu_ref, lv_ref = O.forward(x, sd, eps, True, 0.0, None)
     assert recon.shape == (16, 3, 32, 32)
     assert rel_l2(recon.detach().cpu(), r_ref) <= 2e-2 and rel_l2(mu.detach().cpu(), mu_ref) <= 5e-2
+
+
+@pytest.mark.parametrize("N,L,S,Cin,Cout", [(5, 64, 16, 3, 3), (3, 64, 32, 4, 3), (3, 64, 32, 3, 1), (2, 64, 48, 3, 3), (2, 192, 32, 3, 3)])
+def test_other_sizes_and_channel_counts_against_the_oracle(N, L, S, Cin, Cout):
+    """2x2 bottleneck (16x16 images), four input channels, one output channel, a 6x6 bottleneck, a latent size that is
+    not a power of two: train-mode forward against the oracle"""
+    from vae_amd.vae import VAEConv
+    torch.manual_seed(1)
+    m = VAEConv(Cin, Cout, L, 0.0, S).to(DEV).train()
+    m.rng_seed, m.rank, m.rng_step = 3, 0, 0
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    x = torch.rand(N, Cin, S, S, generator=torch.Generator().manual_seed(S))
+    recon, mu, logvar = m(x.to(DEV))
+    eps = torch.from_numpy(O.philox_normal(N * L, 3, O.STREAM_EPS, 0, 0)).view(N, L)
+    with torch.no_grad():
+        r_ref, mu_ref, lv_ref = O.forward(x, sd, eps, True, 0.0, None)
+    assert m.chw == (256, S // 8, S // 8) and recon.shape == (N, Cout, S, S)
+    assert rel_l2(recon.detach().cpu(), r_ref) <= 2e-2 and rel_l2(mu.detach().cpu(), mu_ref) <= 5e-2
+    assert rel_l2(logvar.detach().cpu(), lv_ref) <= 8e-2
+
+
+def test_image_size_8_fails_like_the_reference():
+    """a 1x1 bottleneck: the constructor's train-mode dummy forward (vae/models/vae.py:76-86) runs BatchNorm on one
+    value per channel, which torch refuses; the same error is raised here"""
+    from vae_amd.vae import VAEConv
+    with pytest.raises(ValueError, match="Expected more than 1 value per channel"):
+        VAEConv(3, 3, 64, 0.0, 8)
