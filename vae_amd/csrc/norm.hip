@@ -105,16 +105,25 @@ __global__ __launch_bounds__(1024) void sum_partials_kernel(const float* __restr
     __shared__ double red[32][33];
     const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
-    double s0 = 0.0, s1 = 0.0;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     if (c < ncols) {
         int r = rg;
-        for (; r + 32 < rows; r += 64) {           // two loads in flight per lane
+        for (; r + 224 < rows; r += 256) {         // eight loads in flight per lane: the launch is a chain of round trips
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = partial[(long)(r + 32 * i) * ld + c];
+            s0 += (double)v[0] + (double)v[4];
+            s1 += (double)v[1] + (double)v[5];
+            s2 += (double)v[2] + (double)v[6];
+            s3 += (double)v[3] + (double)v[7];
+        }
+        for (; r + 32 < rows; r += 64) {
             s0 += (double)partial[(long)r * ld + c];
             s1 += (double)partial[(long)(r + 32) * ld + c];
         }
         if (r < rows) s0 += (double)partial[(long)r * ld + c];
     }
-    red[rg][cl] = s0 + s1;
+    red[rg][cl] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (rg == 0 && c < ncols) {
         double s = 0.0;
@@ -616,7 +625,7 @@ extern "C" int vae_bn_act_bwd_blocks(int n_img, int H, int W, int C, int pool) {
     const long items = (long)n_img * H * W / (pool ? 4 : 1) * (C / 8);
     long b = (items + 255) / 256;
     if (b < 1) b = 1;
-    if (b > 512) b = 512;
+    if (b > 1024) b = 1024;
     return (int)b;
 }
 
