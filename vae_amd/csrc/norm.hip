@@ -84,11 +84,20 @@ __global__ __launch_bounds__(256) void stats_stage1_kernel(float* __restrict__ p
     const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
     float s = 0.f, q = 0.f;
-    if (c < ncols)
-        for (int r = blockIdx.y + 32 * rg; r < rows; r += 128) {
+    if (c < ncols) {
+        int r = blockIdx.y + 32 * rg;
+        for (; r + 384 < rows; r += 512) {          // four rows of both arrays in flight
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a[i] = psum[(long)(r + 128 * i) * ncols + c]; b[i] = psq[(long)(r + 128 * i) * ncols + c]; }
+            s += (a[0] + a[1]) + (a[2] + a[3]);
+            q += (b[0] + b[1]) + (b[2] + b[3]);
+        }
+        for (; r < rows; r += 128) {
             s += psum[(long)r * ncols + c];
             q += psq[(long)r * ncols + c];
         }
+    }
     red[0][rg][cl] = s;
     red[1][rg][cl] = q;
     __syncthreads();
