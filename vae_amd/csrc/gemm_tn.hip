@@ -577,7 +577,15 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
     const int n = (int)(e % N);
     const long m = e / N;
     float4 a = bias ? *(const float4*)(bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s = 0; s < nsplit; ++s) {
+    int s = 0;
+    for (; s + 3 < nsplit; s += 4) {       // four slabs requested at once, added in slab order
+        float4 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = *(const float4*)(slab + (long)(s + i) * mn + e);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { a.x += v[i].x; a.y += v[i].y; a.z += v[i].z; a.w += v[i].w; }
+    }
+    for (; s < nsplit; ++s) {
         const float4 v = *(const float4*)(slab + (long)s * mn + e);
         a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
     }
