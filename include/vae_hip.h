@@ -254,6 +254,16 @@ int vae_gn_act_bwd(const void* gin, const void* y, const float* gamma, const flo
                    const float* mean_rstd, float* chan_partial, float* sums, void* dy, int n_img,
                    int H, int W, int C, int groups, int pool, double p_drop, const void* keep_mask,
                    unsigned long long seed, unsigned step, unsigned stream_id, unsigned rank, void* stream);
+/* ---- nn.MaxPool2d(2) on its own, vae/models/vae.py:35,38,41 (the model's pooling is fused into the
+ *      activation kernels above; the drafts' U-Net keeps the unpooled tensor too,
+ *      vae/practice/vae_original.py:142-149) --------------------------------------------------------------
+ * x [n,H,W,C] bf16 -> out [n,H/2,W/2,C]; route (optional, [n,H/2,W/2,C] uint8) receives the window position
+ * (scan order, first maximum wins) of each maximum. */
+int vae_maxpool2_fwd(const void* x, void* out, void* route, int n_img, int H, int W, int C, void* stream);
+/* dx [n,H,W,C] = gout at each window's maximum, 0 elsewhere; the maximum comes from route when given
+ * (x may then be null), else it is recomputed from x. */
+int vae_maxpool2_bwd(const void* gout, const void* x, const void* route, void* dx, int n_img, int H, int W,
+                     int C, void* stream);
 /* relu(bn1(.)) -> nn.Conv2d(64, Cout, 1) -> sigmoid, vae/models/vae.py:74,121-122.
  * y [n,H,W,64] bf16, w [Cout][64] f32, recon [n,Cout,H,W] f32 (NCHW, the module output). */
 int vae_head_fwd(const void* y, const float* scale, const float* shift, const float* w,

@@ -57,6 +57,8 @@ SIGNATURES = {
     "vae_bn_act_bwd_route": (None, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_double, P,
                                     c_ulonglong, c_uint, c_uint, c_uint, P]),
     "vae_bn_act_bwd_blocks": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "vae_maxpool2_fwd": (None, [P, P, P, c_int, c_int, c_int, c_int, P]),
+    "vae_maxpool2_bwd": (None, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "vae_gn_act_fwd": (None, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_double, P, c_ulonglong,
                               c_uint, c_uint, c_uint, P]),
     "vae_gn_act_bwd": (None, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_double, P,

@@ -151,3 +151,37 @@ class DoubleConvGN(nn.Module):
             x = x.permute(0, 2, 3, 1).to(torch.bfloat16)
         out = self.forward_nhwc(x, False, keep_mask)
         return out.permute(0, 3, 1, 2).float()
+
+
+class _MaxPool2(torch.autograd.Function):
+    """nn.MaxPool2d(2) on an NHWC bf16 tensor; the backward reads the route bytes the forward left."""
+
+    @staticmethod
+    def forward(ctx, x):
+        n, H, W, C = x.shape
+        x = x.contiguous()
+        out = torch.empty(n, H // 2, W // 2, C, device=x.device, dtype=torch.bfloat16)
+        route = torch.empty(n, H // 2, W // 2, C, device=x.device, dtype=torch.uint8)
+        _lib.call("vae_maxpool2_fwd", x.data_ptr(), out.data_ptr(), route.data_ptr(), n, H, W, C, _lib.current_stream())
+        ctx.save_for_backward(route)
+        ctx.shape = (n, H, W, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        (route,) = ctx.saved_tensors
+        n, H, W, C = ctx.shape
+        g_out = g_out.contiguous()
+        dx = torch.empty(n, H, W, C, device=g_out.device, dtype=torch.bfloat16)
+        _lib.call("vae_maxpool2_bwd", g_out.data_ptr(), None, route.data_ptr(), dx.data_ptr(), n, H, W, C, _lib.current_stream())
+        return dx
+
+
+def maxpool2_nhwc(x):
+    """``nn.MaxPool2d(2)`` for the kernels' layout (NHWC bf16, even H and W, channels a multiple of 8): what the drafts'
+    U-Net encoders apply to a block's output while keeping the unpooled tensor for the skip connection
+    (vae/practice/vae_original.py:142-149)."""
+    if not x.is_cuda or x.dtype != torch.bfloat16:
+        raise RuntimeError("maxpool2_nhwc takes an NHWC bf16 tensor on the GPU (no CPU fallback)")
+    _lib.load()
+    return _MaxPool2.apply(x)
