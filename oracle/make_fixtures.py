@@ -11,6 +11,7 @@ torchinfo) are absent from the image and are registered as empty stubs.
 import os
 import sys
 import types
+from collections import OrderedDict
 from types import SimpleNamespace
 
 import numpy as np
@@ -204,9 +205,50 @@ def case_double_conv_gn(name, cin, cout, n, size, p, seed):
     print(f"wrote {path}: {os.path.getsize(path) / 1e6:.2f} MB")
 
 
+def case_unet256(name, latent, size, n, p, seed, kl_weight=0.5):
+    """the reference's U-Net VAE itself (vae/practice/vae_original.py:77-181) in train mode with eps injected
+    (same expression as its reparameterize, :178-181) and its vae_loss_mse (:527-532): logits, mu, logvar, loss,
+    dropout masks of the seven blocks, gradient digests.  Weights are reproduced from the seed by
+    construct_state_unet256 + perturb_gn_params; the fixture keeps digests of them."""
+    import vae.practice.vae_original as ref_unet
+    torch.manual_seed(seed)
+    m = ref_unet.VAEUnet256(3, latent, p, size)
+    sd = O.perturb_gn_params(OrderedDict((k, v.clone()) for k, v in m.state_dict().items()), seed)
+    m.load_state_dict(sd)
+    m.train()
+    x, eps = O.make_inputs(n, 3, size, latent, seed)
+    m.reparameterize = lambda mu, logvar: mu + torch.exp(0.5 * logvar) * eps
+    masks, hooks = {}, []
+    for bname, mod in m.named_children():
+        if isinstance(mod, ref_unet.DoubleConv):
+            hooks.append(mod.double_conv[6].register_forward_hook(
+                lambda _m, inp, outp, bname=bname: masks.__setitem__(bname, ((outp != 0) | (inp[0] == 0)).to(torch.uint8))))
+    torch.manual_seed(seed + 7)          # the dropout draws of this forward
+    out, mu, logvar = m(x)
+    loss = ref_unet.vae_loss_mse(x, out, mu, logvar, kl_weight)
+    loss.backward()
+    for h in hooks:
+        h.remove()
+    res = {"cfg/latent": latent, "cfg/size": size, "cfg/n": n, "cfg/p": p, "cfg/seed": seed, "cfg/kl_weight": kl_weight,
+           "out": out.detach().numpy().copy(), "mu": mu.detach().numpy().copy(), "logvar": logvar.detach().numpy().copy(),
+           "loss": np.float64(loss.item())}
+    for k, v in masks.items():
+        res[f"mask/{k}/shape"] = np.array(v.shape)
+        res[f"mask/{k}/bits"] = np.packbits(v.numpy().reshape(-1))
+    put_digests(res, "sd", sd)
+    put_digests(res, "grad", {k: v.grad for k, v in m.named_parameters()})
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **res)
+    print(f"wrote {path}: {os.path.getsize(path) / 1e6:.2f} MB")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref_vae, ref_train = import_reference()
+    if "--unet" in sys.argv:        # only the U-Net fixtures
+        case_unet256("unet256_s16", 64, 16, 2, 0.1, 1360)
+        case_unet256("unet256_s32_nodrop", 128, 32, 2, 0.0, 1361, kl_weight=1.0)
+        return
     if "--gn" in sys.argv:          # only the GroupNorm block fixtures (the others stay as committed)
         case_double_conv_gn("gn_block", 8, 64, 3, 8, 0.0, 1350)
         case_double_conv_gn("gn_block_dropout", 8, 64, 2, 8, 0.25, 1351)

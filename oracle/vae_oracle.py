@@ -669,3 +669,128 @@ def loss_and_grads_bf16(x, sd, eps, kind="l1", kl_weight=1.0, p_dropout=0.0, mas
     grads = {k: (g if g is not None else torch.zeros_like(params[k]))
              for k, g in zip(params.keys(), gl)}
     return loss.detach(), recon.detach(), mu.detach(), logvar.detach(), grads, stats
+
+
+# ----------------------------------------------------------------------------
+# The drafts' U-Net VAE (vae/practice/vae_original.py:77-181, class VAEUnet256):
+# three GroupNorm double-conv encoder stages whose UNPOOLED outputs are kept as
+# skip tensors, a middle block, the latent heads, and three decoder stages
+# ConvTranspose2d(k2,s2) -> cat([up, skip], dim=1) -> double conv; the 1x1 head
+# returns logits.
+# ----------------------------------------------------------------------------
+UNET_ENC = (("conv0", None, 64), ("conv1", 64, 128), ("conv2", 128, 256), ("middle", 256, 256))
+UNET_DEC = (("up2", 256, 128, "refine2", 128 + 256, 128), ("up1", 128, 64, "refine1", 64 + 128, 64),
+            ("up0", 64, 64, "refine0", 64 + 64, 64))
+
+
+def unet256_state_shapes(latent_dims=64, image_size=32):
+    """state_dict names and shapes of VAEUnet256, in registration order (vae_original.py:88-119).
+    conv0 takes 3 channels whatever ``in_channels`` says (:88)."""
+    s = image_size // 8
+    flat = 256 * s * s
+    shapes = OrderedDict()
+
+    def block(name, ci, co):
+        shapes[f"{name}.double_conv.0.weight"] = (co, ci, 3, 3)
+        shapes[f"{name}.double_conv.0.bias"] = (co,)
+        shapes[f"{name}.double_conv.1.weight"] = (co,)
+        shapes[f"{name}.double_conv.1.bias"] = (co,)
+        shapes[f"{name}.double_conv.3.weight"] = (co, co, 3, 3)
+        shapes[f"{name}.double_conv.3.bias"] = (co,)
+        shapes[f"{name}.double_conv.4.weight"] = (co,)
+        shapes[f"{name}.double_conv.4.bias"] = (co,)
+
+    for name, ci, co in UNET_ENC:
+        block(name, ci or 3, co)
+    for name in ("fc_mu", "fc_logvar"):
+        shapes[f"{name}.weight"] = (latent_dims, flat)
+        shapes[f"{name}.bias"] = (latent_dims,)
+    shapes["fc_up.weight"] = (flat, latent_dims)
+    shapes["fc_up.bias"] = (flat,)
+    for up, ci, co, ref, rci, rco in UNET_DEC:
+        shapes[f"{up}.weight"] = (ci, co, 2, 2)
+        shapes[f"{up}.bias"] = (co,)
+        block(ref, rci, rco)
+    shapes["head.weight"] = (3, 64, 1, 1)
+    shapes["head.bias"] = (3,)
+    return shapes
+
+
+def construct_state_unet256(latent_dims=64, p_dropout=0.1, image_size=32):
+    """Restates VAEUnet256.__init__ (vae_original.py:78-119), consuming torch's global CPU generator in the same
+    order: the four encoder blocks, the train-mode dummy forward of _get_flattened_shape (:122-138; one Bernoulli
+    mask per block when p > 0, GroupNorm keeps no running state), fc_mu, fc_logvar, their xavier_uniform_(gain=0.1)
+    (:104-105), fc_up, then up / refine pairs and the head."""
+    shapes = unet256_state_shapes(latent_dims, image_size)
+    sd = OrderedDict()
+
+    def conv_like(wname, bname):
+        shp = shapes[wname]
+        fan_in = shp[1] * (shp[2] * shp[3] if len(shp) == 4 else 1)
+        bound = 1.0 / math.sqrt(fan_in)
+        sd[wname] = _uniform(shp, bound)
+        sd[bname] = _uniform(shapes[bname], bound)
+
+    def block(name):
+        for j in (0, 3):
+            conv_like(f"{name}.double_conv.{j}.weight", f"{name}.double_conv.{j}.bias")
+            c = shapes[f"{name}.double_conv.{j + 1}.weight"][0]
+            sd[f"{name}.double_conv.{j + 1}.weight"] = torch.ones(c)
+            sd[f"{name}.double_conv.{j + 1}.bias"] = torch.zeros(c)
+
+    for name, _, _ in UNET_ENC:
+        block(name)
+    if p_dropout > 0:
+        s = image_size
+        for i, (name, _, co) in enumerate(UNET_ENC):
+            F.dropout(torch.zeros(1, co, s, s), p_dropout, True)      # the dummy forward's mask draw
+            if i < 3:
+                s //= 2
+    for name in ("fc_mu", "fc_logvar"):
+        conv_like(f"{name}.weight", f"{name}.bias")
+    for name in ("fc_mu", "fc_logvar"):
+        shp = shapes[f"{name}.weight"]
+        sd[f"{name}.weight"] = _uniform(shp, 0.1 * math.sqrt(6.0 / (shp[0] + shp[1])))
+    conv_like("fc_up.weight", "fc_up.bias")
+    for up, _, _, ref, _, _ in UNET_DEC:
+        conv_like(f"{up}.weight", f"{up}.bias")
+        block(ref)
+    conv_like("head.weight", "head.bias")
+    return OrderedDict((k, sd[k]) for k in shapes)
+
+
+def unet256_forward(x, sd, eps, train=True, p_dropout=0.0, masks=None):
+    """VAEUnet256.forward (vae_original.py:141-175) with eps injected -> (logits, mu, logvar).
+    masks: optional dict block name -> dropout keep mask (7 blocks)."""
+    masks = masks or {}
+    skips = []
+    for i, (name, _, _) in enumerate(UNET_ENC):
+        x = double_conv_gn(x, sd, name, train, p_dropout, masks.get(name))
+        if i < 3:
+            skips.append(x)
+            x = F.max_pool2d(x, 2)
+    n, c, h, w = x.shape
+    m = x.reshape(n, c * h * w)
+    mu = F.linear(m, sd["fc_mu.weight"], sd["fc_mu.bias"])
+    logvar = F.linear(m, sd["fc_logvar.weight"], sd["fc_logvar.bias"])
+    z = reparameterize(mu, logvar, eps)
+    x = torch.tanh(F.linear(z, sd["fc_up.weight"], sd["fc_up.bias"])).view(n, c, h, w)
+    for up, _, _, ref, _, _ in UNET_DEC:
+        u = F.conv_transpose2d(x, sd[f"{up}.weight"], sd[f"{up}.bias"], stride=2)
+        x = double_conv_gn(torch.cat([u, skips.pop()], dim=1), sd, ref, train, p_dropout, masks.get(ref))
+    return F.conv2d(x, sd["head.weight"], sd["head.bias"]), mu, logvar
+
+
+def unet_loss_mse(x, x_hat, mu, logvar, kl_weight):
+    """vae_loss_mse of the draft script (vae_original.py:527-532): squared error on the head's logits."""
+    return (((x_hat - x) ** 2).sum() + kl_weight * kl_sum(mu, logvar)) / x.size(0)
+
+
+def perturb_gn_params(sd, seed: int):
+    """moves every GroupNorm affine away from its (1, 0) init, deterministically in key order (so that fixtures
+    need not store the weights: construct_state_unet256 under the seed + this reproduce them)."""
+    g = torch.Generator().manual_seed(seed + 1)
+    for k in sd:
+        if ".double_conv.1." in k or ".double_conv.4." in k:
+            sd[k] = sd[k] + 0.3 * torch.randn(sd[k].shape, generator=g)
+    return sd
