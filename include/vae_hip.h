@@ -264,6 +264,11 @@ int vae_maxpool2_fwd(const void* x, void* out, void* route, int n_img, int H, in
  * (x may then be null), else it is recomputed from x. */
 int vae_maxpool2_bwd(const void* gout, const void* x, const void* route, void* dx, int n_img, int H, int W,
                      int C, void* stream);
+/* out[c] = sum_r x[r][c] of a [rows][C] bf16 matrix: the bias gradient of a conv / transposed conv from the
+ * gradient of its output (nn.ConvTranspose2d bias in the drafts' U-Net decoders, vae/practice/vae_original.py:110-116,
+ * where no normalisation follows and the gradient is not zero).  partial: vae_colsum_blocks(rows, C) x C floats. */
+int vae_colsum_blocks(long rows, int C);
+int vae_colsum_bf16(const void* x, long rows, int C, float* partial, float* out, void* stream);
 /* relu(bn1(.)) -> nn.Conv2d(64, Cout, 1) -> sigmoid, vae/models/vae.py:74,121-122.
  * y [n,H,W,64] bf16, w [Cout][64] f32, recon [n,Cout,H,W] f32 (NCHW, the module output). */
 int vae_head_fwd(const void* y, const float* scale, const float* shift, const float* w,
@@ -276,6 +281,16 @@ int vae_head_bwd(const float* drecon, const float* recon, const void* y, const f
                  const float* shift, const float* mean, const float* rstd, const float* w,
                  float* partial, float* sums, float* sums_head, void* dy, int n_img, int H, int W,
                  int Cout, void* stream);
+/* nn.Conv2d(64, Cout, 1) alone, logits out: the output layer of the drafts' U-Net models
+ * (vae/practice/vae_original.py:119,173-175; no normalisation in front, no sigmoid behind).
+ * x [n,H,W,64] bf16, w [Cout][64] f32, b [Cout], out [n,Cout,H,W] f32 (NCHW).  Cout in {1, 3, 4}. */
+int vae_conv1x1_out_fwd(const void* x, const float* w, const float* b, float* out, int n_img, int H, int W,
+                        int Cout, void* stream);
+int vae_conv1x1_out_bwd_blocks(int n_img, int H, int W);
+/* its backward: gout [n,Cout,H,W] f32; partial is blocks x (Cout+1)*64 floats of scratch;
+ * sums = [dW[Cout][64] | db(Cout) padded to 64]; dx [n,H,W,64] bf16 (may be null). */
+int vae_conv1x1_out_bwd(const float* gout, const void* x, const float* w, float* partial, float* sums,
+                        void* dx, int n_img, int H, int W, int Cout, void* stream);
 /* torch.tanh backward (vae.py:116): dpre = dx*(1-h^2), colpartial [vae_tanh_bwd_rows(rows)][cols]
  * = per-row-group column sums of dpre (fc_up bias gradient). */
 int vae_tanh_bwd_rows(int rows);

@@ -45,6 +45,26 @@ def test_maxpool2_fwd_bwd(L, n, H, W, C):
         L.call("vae_maxpool2_bwd", L.ptr(gd), None, None, L.ptr(out), n, H, W, C, L.current_stream())
 
 
+@pytest.mark.parametrize("rows,C", [(1, 64), (37, 8), (4096, 64), (100000, 128), (513, 256), (70000, 2048)])
+def test_colsum_bf16(L, rows, C):
+    """bias gradient of a conv / transposed conv with no normalisation behind it: column sums of its output gradient"""
+    g = torch.Generator().manual_seed(rows + C)
+    x = torch.randn(rows, C, generator=g).to(torch.bfloat16)
+    xd = x.to(DEV)
+    nb = L.call("vae_colsum_blocks", rows, C)
+    partial = torch.full((nb, C), float("nan"), device=DEV)
+    out = torch.full((C,), float("nan"), device=DEV)
+    L.call("vae_colsum_bf16", L.ptr(xd), rows, C, L.ptr(partial), L.ptr(out), L.current_stream())
+    ref = x.double().sum(0)
+    scale = x.double().abs().sum(0).clamp_min(1.0)
+    assert float(((out.double().cpu() - ref).abs() / scale).max()) <= 1e-6
+    out2 = torch.empty_like(out)
+    L.call("vae_colsum_bf16", L.ptr(xd), rows, C, L.ptr(partial), L.ptr(out2), L.current_stream())
+    assert torch.equal(out, out2)          # fixed summation order
+    with pytest.raises(RuntimeError, match="divisor of 256"):
+        L.call("vae_colsum_bf16", L.ptr(xd), rows, 24, L.ptr(partial), L.ptr(out), L.current_stream())
+
+
 def test_unet_encoder_stage_keeps_the_skip_tensor():
     """block -> (skip tensor, pooled tensor) as the drafts' U-Net encoder does (vae/practice/vae_original.py:142-146):
     the separate pool equals the pool fused into the block, and gradients flow back through both uses"""

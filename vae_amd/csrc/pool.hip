@@ -94,6 +94,33 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const bf16_t* __restr
     }
 }
 
+// column sums of a [rows][C] bf16 matrix (the bias gradient of a conv / transposed conv whose output gradient it is):
+// partial[block][C] per workgroup, folded in a fixed order by the caller's second launch
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ x, long rows, int C,
+                                                          float* __restrict__ partial) {
+    __shared__ float red[256][8];
+    const int cgs = C >> 3, cshift = __ffs(cgs) - 1;
+    const int c0 = (threadIdx.x & (cgs - 1)) * 8;
+    float a[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = 0.f;
+    const long rstride = ((long)gridDim.x * 256) >> cshift;
+    for (long r = ((long)blockIdx.x * 256 + threadIdx.x) >> cshift; r < rows; r += rstride) {
+        float v[8];
+        load8(x + r * C + c0, v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] += v[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[threadIdx.x][i] = a[i];
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f;
+        for (int t = c >> 3; t < 256; t += cgs) s += red[t][c & 7];
+        partial[(long)blockIdx.x * C + c] = s;
+    }
+}
+
 static int pool_grid(long items) {
     long b = (items + 255) / 256;
     if (b < 1) b = 1;
@@ -136,4 +163,24 @@ extern "C" int vae_maxpool2_bwd(const void* gout, const void* x, const void* rou
                            (const bf16_t*)x, (const uint8_t*)route, (bf16_t*)dx, g, items);
     VAE_LAUNCH_CHECK("maxpool2_bwd_kernel");
     return 0;
+}
+
+extern "C" int vae_colsum_blocks(long rows, int C) {
+    long b = (rows * (C / 8) + 255) / 256;
+    if (b < 1) b = 1;
+    if (b > 512) b = 512;
+    return (int)b;
+}
+
+extern "C" int vae_colsum_bf16(const void* x, long rows, int C, float* partial, float* out, void* stream) {
+    VAE_CHECK(x && partial && out && rows > 0, "vae_colsum_bf16: bad arguments");
+    VAE_CHECK(C > 0 && C % 8 == 0 && 256 % (C / 8) == 0, "vae_colsum_bf16: C=%d must be 8 * a divisor of 256", C);
+    const int nb = vae_colsum_blocks(rows, C);
+    hipStream_t s = (hipStream_t)stream;
+    {
+        ProfScope prof("colsum_bf16_kernel", 0.0, 2.0 * rows * C, s);
+        hipLaunchKernelGGL(colsum_bf16_kernel, dim3(nb), dim3(256), 0, s, (const bf16_t*)x, rows, C, partial);
+        VAE_LAUNCH_CHECK("colsum_bf16_kernel");
+    }
+    return vae_sum_partials(partial, nb, C, out, 1.0f, stream);
 }
