@@ -23,12 +23,13 @@ WGRAD_PLAIN, WGRAD_CONVT = 0, 2
 
 
 def _wgrad(P, Q, M, N, K, ldp, ldq, mode, H, W, taps, out, dims4, strides4, s):
-    """out (parameter layout) = fold of the split-K slabs of dW[m][tap][n] = sum_k P[k][m] Q[k(+tap)][n]"""
+    """out (parameter layout) = fold of the split-K slabs of dW[m][tap][n] = sum_k P[k][m] Q[k(+tap)][n].
+    dims4: the slab's own dims (walked in order, coalesced); strides4: where each of them lands in ``out``."""
     ns = _lib.call("vae_wgrad_ksplit", M, N, taps, K)
     slab = torch.empty(ns, M, taps, N, device=P.device)
     _lib.call("vae_wgrad_gemm", P.data_ptr(), Q.data_ptr(), slab.data_ptr(), M, N, K, ldp, ldq, mode, H, W, ns, s)
-    _lib.call("vae_reduce_slabs", slab.data_ptr(), ns, M * taps * N, out.data_ptr(), _lib.long4(*dims4), _lib.long4(*strides4),
-              0, 0, s)
+    _lib.call("vae_reduce_slabs_scatter", slab.data_ptr(), ns, M * taps * N, 0, out.data_ptr(), _lib.long4(*dims4),
+              _lib.long4(*strides4), None, 0, 0, s)
     return out
 
 
@@ -72,7 +73,7 @@ class _ConvT2x2(torch.autograd.Function):
             _lib.call("vae_convt2x2_dgrad_gemm", dy.data_ptr(), wd.data_ptr(), dx.data_ptr(), n, H, W, Ci, Co, s)
         dw = torch.empty(Ci, Co, 2, 2, device=x.device)
         # slab [co][tap][ci] -> parameter [ci][co][tap]
-        _wgrad(dy, x, Co, Ci, n * H * W, Co, Ci, WGRAD_CONVT, H, W, 4, dw, (Ci, Co, 4, 1), (1, 4 * Ci, Ci, 0), s)
+        _wgrad(dy, x, Co, Ci, n * H * W, Co, Ci, WGRAD_CONVT, H, W, 4, dw, (Co, 4, Ci, 1), (4, 1, 4 * Co, 0), s)
         db = _colsum(dy.view(-1, Co), s)
         return dx, dw, db
 
@@ -113,7 +114,7 @@ class _LatentHeads(torch.autograd.Function):
                   EPI_BF16, s)
         dw = torch.empty(2 * L, Fdim, device=a.device)
         # slab [row][f = p*C + c] -> parameter [row][c*hw + p]
-        _wgrad(dcat, a, 2 * L, Fdim, M, 2 * L, Fdim, WGRAD_PLAIN, 1, 1, 1, dw, (2 * L, C, hw, 1), (Fdim, 1, C, 0), s)
+        _wgrad(dcat, a, 2 * L, Fdim, M, 2 * L, Fdim, WGRAD_PLAIN, 1, 1, 1, dw, (2 * L, hw, C, 1), (Fdim, 1, hw, 0), s)
         db = dcat32.sum(0)
         return da, dw[:L], db[:L], dw[L:], db[L:], None, None
 
@@ -182,7 +183,7 @@ class _FcUpTanh(torch.autograd.Function):
                   EPI_F32, s)
         dw = torch.empty(Fdim, L, device=z.device)
         # slab [f = p*C + c][l] -> parameter [c*hw + p][l]
-        _wgrad(dpre, z, Fdim, L, M, Fdim, L, WGRAD_PLAIN, 1, 1, 1, dw, (C, hw, L, 1), (L, C * L, 1, 0), s)
+        _wgrad(dpre, z, Fdim, L, M, Fdim, L, WGRAD_PLAIN, 1, 1, 1, dw, (hw, C, L, 1), (L, hw * L, 1, 0), s)
         return dz.to(torch.bfloat16), dw, db, None, None
 
 

@@ -38,20 +38,23 @@ def _conv_wgrad(dy, x, n, H, W, Ci, Co, s):
         ns = _lib.call("vae_wgrad_ksplit", Co, 64, 2, M)
         slab = torch.empty(ns, Co, 2, 64, device=dy.device)
         _lib.call("vae_wgrad_gemm", dy.data_ptr(), x.data_ptr(), slab.data_ptr(), Co, 64, M, Co, 8, 3, H, W, ns, s)
-        _lib.call("vae_reduce_slabs", slab.data_ptr(), ns, Co * 128, dw.data_ptr(), _lib.long4(Co, Ci, 9, 1),
-                  _lib.long4(128, 1, 8, 0), 0, 0, s)
+        # slab [co][16 tap slots][8 channel slots] -> weight [co][ci][tap]; the padding slots are skipped
+        _lib.call("vae_reduce_slabs_scatter", slab.data_ptr(), ns, Co * 128, 0, dw.data_ptr(), _lib.long4(Co, 16, 8, 1),
+                  _lib.long4(9 * Ci, 1, 9, 0), _lib.long4(Co, 9, Ci, 1), 0, 0, s)
     elif _lib.call("vae_conv3_wgrad_patch_ok", H, W, Ci, Co) == 1:
         ns = _lib.call("vae_conv3_wgrad_patch_ksplit", n, H, W, Ci, Co)
         slab = torch.empty(ns, Co, 9, Ci, device=dy.device)
         _lib.call("vae_conv3_wgrad_patch", dy.data_ptr(), x.data_ptr(), slab.data_ptr(), n, H, W, Ci, Co, ns, s)
-        _lib.call("vae_reduce_slabs", slab.data_ptr(), ns, 9 * Co * Ci, dw.data_ptr(), _lib.long4(Co, Ci, 9, 1),
-                  _lib.long4(9 * Ci, 1, Ci, 0), 0, 0, s)
+        # walk the slab [co][tap][ci] in its own order (coalesced reads), scatter into the weight's [co][ci][tap]
+        _lib.call("vae_reduce_slabs_scatter", slab.data_ptr(), ns, 9 * Co * Ci, 0, dw.data_ptr(), _lib.long4(Co, 9, Ci, 1),
+                  _lib.long4(9 * Ci, 1, 9, 0), None, 0, 0, s)
     else:
         ns = _lib.call("vae_wgrad_ksplit", Co, Ci, 9, M)
         slab = torch.empty(ns, Co, 9, Ci, device=dy.device)
         _lib.call("vae_wgrad_gemm", dy.data_ptr(), x.data_ptr(), slab.data_ptr(), Co, Ci, M, Co, Ci, 1, H, W, ns, s)
-        _lib.call("vae_reduce_slabs", slab.data_ptr(), ns, 9 * Co * Ci, dw.data_ptr(), _lib.long4(Co, Ci, 9, 1),
-                  _lib.long4(9 * Ci, 1, Ci, 0), 0, 0, s)
+        # walk the slab [co][tap][ci] in its own order (coalesced reads), scatter into the weight's [co][ci][tap]
+        _lib.call("vae_reduce_slabs_scatter", slab.data_ptr(), ns, 9 * Co * Ci, 0, dw.data_ptr(), _lib.long4(Co, 9, Ci, 1),
+                  _lib.long4(9 * Ci, 1, 9, 0), None, 0, 0, s)
     return dw
 
 
