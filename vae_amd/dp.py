@@ -6,8 +6,8 @@ data-parallel step the MI355X build adds.  Parameters, optimizer state and Batch
 stats are replicated; BatchNorm batch statistics stay per rank (the single-process semantics
 at the local batch).  The backward pass finishes layers in three stages (decoder + latent
 heads, conv4+conv3, conv2+conv1); each stage's slice of the flat gradient buffer is contiguous,
-so its buckets are plain views (no copy) and are all-reduced on a side stream while the next
-stage computes."""
+so its buckets are plain views (no copy) and are all-reduced on the process group's own stream
+while the next stage computes."""
 from __future__ import annotations
 
 from typing import List, Sequence, Tuple
@@ -38,13 +38,15 @@ class BucketedReducer:
     """all-reduce (mean) of `flat_grads` in per-stage buckets."""
 
     def __init__(self, flat_grads: torch.Tensor, ranges: Sequence[Tuple[int, int]], bucket_bytes: int = 16 << 20,
-                 group=None):
+                 group=None, side_stream: bool = False):
         self.flat = flat_grads
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.buckets = [split_buckets(a, b, max(1, bucket_bytes // flat_grads.element_size())) for a, b in ranges]
         self.cuda = flat_grads.is_cuda
-        self.comm_stream = torch.cuda.Stream() if self.cuda else None
+        # torch's NCCL process group runs a collective on its own stream, ordered after the stream it was issued from;
+        # side_stream=False issues from the compute stream itself (one hand-over fewer per stage)
+        self.comm_stream = torch.cuda.Stream() if self.cuda and side_stream else None
         self.handles = []
         backend = dist.get_backend(group) if dist.is_initialized() else ""
         self.avg_op = backend == "nccl"          # RCCL has ncclAvg; gloo needs SUM then a divide
@@ -54,7 +56,7 @@ class BucketedReducer:
         if self.world == 1:
             return
         op = dist.ReduceOp.AVG if self.avg_op else dist.ReduceOp.SUM
-        if self.cuda:
+        if self.cuda and self.comm_stream is not None:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
