@@ -151,3 +151,24 @@ def test_unet_trains_with_philox_streams():
         losses.append(loss.item())
     assert all(torch.isfinite(torch.tensor(losses)))
     assert losses[-1] < 0.8 * losses[0], losses
+
+
+def test_draft_losses_against_their_formulas():
+    """vae_loss_mse / vae_loss_bce of the draft script (vae/practice/vae_original.py:513-532) and their gradients"""
+    from vae_amd.unet import vae_loss_bce, vae_loss_mse
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(6, 3, 16, 16, generator=g)
+    logits = (4 * torch.randn(6, 3, 16, 16, generator=g)).requires_grad_(True)      # some beyond the +-10 clamp
+    mu = torch.randn(6, 64, generator=g).requires_grad_(True)
+    lv = (0.5 * torch.randn(6, 64, generator=g)).requires_grad_(True)
+    kl = -0.5 * torch.sum(1 + lv - mu.pow(2) - lv.exp())
+    refs = {"bce": F.binary_cross_entropy_with_logits(logits.clamp(-10, 10), x, reduction="mean") + kl,
+            "mse": (F.mse_loss(logits, x, reduction="sum") + 0.3 * kl) / 6}
+    for kind, ref in refs.items():
+        gr = torch.autograd.grad(ref, (logits, mu, lv), retain_graph=True)
+        d = [t.detach().to(DEV).requires_grad_(True) for t in (logits, mu, lv)]
+        got = vae_loss_bce(x.to(DEV), *d) if kind == "bce" else vae_loss_mse(x.to(DEV), *d, 0.3)
+        assert abs(got.item() - ref.item()) <= 1e-5 * abs(ref.item()), kind
+        got.backward()
+        for a, b in zip(d, gr):
+            assert rel_l2(a.grad.cpu(), b) <= 1e-5, kind

@@ -76,10 +76,10 @@ class _ElboLoss(torch.autograd.Function):
     in the same pass that computes it."""
 
     @staticmethod
-    def forward(ctx, recon, target, mu, logvar, kind, kl_weight):
+    def forward(ctx, recon, target, mu, logvar, kind, kl_weight, denom=None):
         recon, target = recon.contiguous(), target.contiguous()
         mu, logvar = mu.contiguous(), logvar.contiguous()
-        n, batch = recon.numel(), recon.size(0)
+        n, batch = recon.numel(), float(denom or recon.size(0))      # denom: what the sum is divided by (default: the batch)
         s = _lib.current_stream()
         grid = _lib.call("vae_recon_loss_grid", n)
         partial = torch.empty(grid, device=recon.device)
@@ -109,7 +109,7 @@ class _ElboLoss(torch.autograd.Function):
         dmu, dlv = torch.empty_like(mu), torch.empty_like(logvar)
         _lib.call("vae_reparam_kl_bwd", None, mu.data_ptr(), logvar.data_ptr(), mu.data_ptr(), None, None, ctx.kl_scale,
                   dmu.data_ptr(), dlv.data_ptr(), None, nl, mu.size(-1), 0, 0, 0, _lib.current_stream())
-        return d_recon, None, dmu * g, dlv * g, None, None
+        return d_recon, None, dmu * g, dlv * g, None, None, None
 
 
 def vae_loss(input, target, mu: torch.Tensor, logvar: torch.Tensor, loss: Callable, lpips_fn, config):

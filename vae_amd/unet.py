@@ -328,3 +328,14 @@ def vae_loss_mse(x, x_hat, mu, logvar, kl_weight):
     on the head's logits, through the fused loss kernels."""
     from .train import Config, vae_loss
     return vae_loss(x_hat, x, mu, logvar, "mse", None, Config(kl_weight=float(kl_weight), percep_weight=0.0))
+
+
+def vae_loss_bce(x, x_hat, mu, logvar):
+    """``vae_loss_bce`` of the draft script (vae/practice/vae_original.py:513-518):
+    mean over all elements of BCE-with-logits on logits clamped to [-10, 10], plus the KL SUM with weight 1 (no division
+    by the batch) -- the fused loss kernels with the element count as the divisor and as the KL weight."""
+    from .train import RECON_KINDS, _ElboLoss
+    if not x_hat.is_cuda:
+        raise RuntimeError("vae_loss_bce runs on the GPU only (no CPU fallback)")
+    n = x_hat.numel()
+    return _ElboLoss.apply(x_hat, x, mu, logvar, RECON_KINDS["bce_logits"], float(n), float(n))
