@@ -38,7 +38,9 @@ def check_bf16(got, ref, what, rtol=4e-3):
 
 
 _GN_CASES = [(4, 8, 8, 64, 0, 0.0), (3, 8, 8, 128, 1, 0.0), (2, 16, 16, 64, 1, 0.1), (5, 4, 4, 256, 0, 0.1), (2, 6, 10, 128, 1, 0.3),
-             (1, 32, 32, 64, 1, 0.1), (70, 2, 2, 256, 1, 0.0)]
+             (1, 32, 32, 64, 1, 0.1), (70, 2, 2, 256, 1, 0.0),
+             # 512 and 1024 channels (the deeper U-Net draft): 64 and 128 channel groups, the latter two waves wide
+             (3, 4, 4, 512, 1, 0.1), (3, 2, 2, 1024, 0, 0.0), (2, 4, 6, 1024, 1, 0.2)]
 
 
 @pytest.mark.parametrize("n,H,W,C,pool,p,inject", [c + (i,) for c in _GN_CASES for i in (False, True) if not (i and c[5] == 0)])

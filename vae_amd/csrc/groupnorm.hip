@@ -18,7 +18,7 @@
 namespace vae {
 
 constexpr int GN_T = 512;          // threads per workgroup
-constexpr int GN_MAXC = 512;
+constexpr int GN_MAXC = 1024;
 constexpr int GN_MAXG = 32;
 
 struct GnGeom {
@@ -39,13 +39,20 @@ __device__ __forceinline__ void gn_image_stats(const bf16_t* __restrict__ yimg, 
     }
     // fold inside the wave first (a fixed shuffle tree): lanes that share a channel group sit cgs apart, and the
     // cpg channel groups of one GroupNorm group are neighbours
+    // (with more than 64 channel groups -- C > 512 -- a wave holds only some of the GroupNorm groups: the slots of the
+    // others stay zero)
     const int cgs = g.C >> 3, cpg = cgs / g.G;
     for (int o = 32; o >= cgs; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
     for (int o = cpg >> 1; o >= 1; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane < cgs && (lane & (cpg - 1)) == 0) {
-        red[wave * g.G + lane / cpg] = s;
-        red[GN_T + wave * g.G + lane / cpg] = q;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, cg = threadIdx.x & (cgs - 1);
+    if (cgs > 64) {
+        red[threadIdx.x] = 0.f;
+        red[GN_T + threadIdx.x] = 0.f;
+        __syncthreads();
+    }
+    if (lane < cgs && (cg & (cpg - 1)) == 0) {
+        red[wave * g.G + cg / cpg] = s;
+        red[GN_T + wave * g.G + cg / cpg] = q;
     }
     __syncthreads();
     if (threadIdx.x < g.G) {
@@ -258,7 +265,7 @@ static int gn_check(const char* who, int n_img, int H, int W, int C, int G, int 
     if (int e = check_geom(who, n_img, H, W, C, pool)) return e;
     VAE_CHECK(G >= 1 && G <= GN_MAXG && C % (8 * G) == 0, "%s: C=%d must be a multiple of 8 * groups (groups=%d, at most %d)",
               who, C, G, GN_MAXG);
-    VAE_CHECK(C <= GN_MAXC && GN_T % (C / 8) == 0, "%s: C=%d not supported (at most %d)", who, C, GN_MAXC);
+    VAE_CHECK(C <= GN_MAXC && GN_T % (C / 8) == 0 && C / 8 / G <= 64, "%s: C=%d not supported (at most %d)", who, C, GN_MAXC);
     return 0;
 }
 
