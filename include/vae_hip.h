@@ -281,6 +281,9 @@ int vae_head_bwd(const float* drecon, const float* recon, const void* y, const f
                  const float* shift, const float* mean, const float* rstd, const float* w,
                  float* partial, float* sums, float* sums_head, void* dy, int n_img, int H, int W,
                  int Cout, void* stream);
+/* torch.clamp(x, lo, hi) on fp32 (logvar in the deeper U-Net draft, vae/practice/vae_original.py:390) and its
+ * backward: g null -> out = clamp(x); g given -> out = g where lo <= x <= hi, else 0. */
+int vae_clamp_f32(const float* x, const float* g, float lo, float hi, float* out, long n, void* stream);
 /* nn.Conv2d(64, Cout, 1) alone, logits out: the output layer of the drafts' U-Net models
  * (vae/practice/vae_original.py:119,173-175; no normalisation in front, no sigmoid behind).
  * x [n,H,W,64] bf16, w [Cout][64] f32, b [Cout], out [n,Cout,H,W] f32 (NCHW).  Cout in {1, 3, 4}. */

@@ -205,15 +205,17 @@ def case_double_conv_gn(name, cin, cout, n, size, p, seed):
     print(f"wrote {path}: {os.path.getsize(path) / 1e6:.2f} MB")
 
 
-def case_unet256(name, latent, size, n, p, seed, kl_weight=0.5):
+def case_unet(name, latent, size, n, p, seed, kl_weight=0.5, variant="256", logvar_shift=0.0):
     """the reference's U-Net VAE itself (vae/practice/vae_original.py:77-181) in train mode with eps injected
     (same expression as its reparameterize, :178-181) and its vae_loss_mse (:527-532): logits, mu, logvar, loss,
     dropout masks of the seven blocks, gradient digests.  Weights are reproduced from the seed by
-    construct_state_unet256 + perturb_gn_params; the fixture keeps digests of them."""
+    construct_state_unet + perturb_gn_params; the fixture keeps digests of them."""
     import vae.practice.vae_original as ref_unet
     torch.manual_seed(seed)
-    m = ref_unet.VAEUnet256(3, latent, p, size)
+    m = getattr(ref_unet, "VAEUnet" + variant)(3, latent, p, size)
     sd = O.perturb_gn_params(OrderedDict((k, v.clone()) for k, v in m.state_dict().items()), seed)
+    if logvar_shift:                    # spreads logvar so that the [-5, 5] clamp of VAEUnet1024 binds on some entries
+        sd["fc_logvar.bias"] = sd["fc_logvar.bias"] + logvar_shift * torch.linspace(-1, 1, latent)
     m.load_state_dict(sd)
     m.train()
     x, eps = O.make_inputs(n, 3, size, latent, seed)
@@ -230,6 +232,7 @@ def case_unet256(name, latent, size, n, p, seed, kl_weight=0.5):
     for h in hooks:
         h.remove()
     res = {"cfg/latent": latent, "cfg/size": size, "cfg/n": n, "cfg/p": p, "cfg/seed": seed, "cfg/kl_weight": kl_weight,
+           "cfg/variant": variant, "cfg/logvar_shift": logvar_shift,
            "out": out.detach().numpy().copy(), "mu": mu.detach().numpy().copy(), "logvar": logvar.detach().numpy().copy(),
            "loss": np.float64(loss.item())}
     for k, v in masks.items():
@@ -246,8 +249,9 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     ref_vae, ref_train = import_reference()
     if "--unet" in sys.argv:        # only the U-Net fixtures
-        case_unet256("unet256_s16", 64, 16, 2, 0.1, 1360)
-        case_unet256("unet256_s32_nodrop", 128, 32, 2, 0.0, 1361, kl_weight=1.0)
+        case_unet("unet256_s16", 64, 16, 2, 0.1, 1360)
+        case_unet("unet256_s32_nodrop", 128, 32, 2, 0.0, 1361, kl_weight=1.0)
+        case_unet("unet1024_s32", 64, 32, 2, 0.1, 1362, kl_weight=0.5, variant="1024", logvar_shift=8.0)
         return
     if "--gn" in sys.argv:          # only the GroupNorm block fixtures (the others stay as committed)
         case_double_conv_gn("gn_block", 8, 64, 3, 8, 0.0, 1350)

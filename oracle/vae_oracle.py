@@ -681,13 +681,20 @@ def loss_and_grads_bf16(x, sd, eps, kind="l1", kl_weight=1.0, p_dropout=0.0, mas
 UNET_ENC = (("conv0", None, 64), ("conv1", 64, 128), ("conv2", 128, 256), ("middle", 256, 256))
 UNET_DEC = (("up2", 256, 128, "refine2", 128 + 256, 128), ("up1", 128, 64, "refine1", 64 + 128, 64),
             ("up0", 64, 64, "refine0", 64 + 64, 64))
+# the five-level sibling, class VAEUnet1024 (vae_original.py:184-403; the second of its two __init__ bodies, :295-340,
+# is the one Python keeps): default init of the latent heads, logvar clamped to [-5, 5] before use and return (:390)
+UNET1024_ENC = (("conv0", None, 64), ("conv1", 64, 128), ("conv2", 128, 256), ("conv3", 256, 512), ("middle", 512, 1024))
+UNET1024_DEC = (("up3", 1024, 512, "refine3", 1024, 512), ("up2", 512, 256, "refine2", 512, 256),
+                ("up1", 256, 128, "refine1", 256, 128), ("up0", 128, 64, "refine0", 128, 64))
+UNET_VARIANTS = {"256": (UNET_ENC, UNET_DEC, True, None), "1024": (UNET1024_ENC, UNET1024_DEC, False, (-5.0, 5.0))}
 
 
-def unet256_state_shapes(latent_dims=64, image_size=32):
-    """state_dict names and shapes of VAEUnet256, in registration order (vae_original.py:88-119).
+def unet_state_shapes(variant="256", latent_dims=64, image_size=32):
+    """state_dict names and shapes of VAEUnet256 / VAEUnet1024, in registration order (vae_original.py:88-119,305-340).
     conv0 takes 3 channels whatever ``in_channels`` says (:88)."""
-    s = image_size // 8
-    flat = 256 * s * s
+    enc, dec, _, _ = UNET_VARIANTS[variant]
+    s = image_size >> (len(enc) - 1)
+    flat = enc[-1][2] * s * s
     shapes = OrderedDict()
 
     def block(name, ci, co):
@@ -700,14 +707,14 @@ def unet256_state_shapes(latent_dims=64, image_size=32):
         shapes[f"{name}.double_conv.4.weight"] = (co,)
         shapes[f"{name}.double_conv.4.bias"] = (co,)
 
-    for name, ci, co in UNET_ENC:
+    for name, ci, co in enc:
         block(name, ci or 3, co)
     for name in ("fc_mu", "fc_logvar"):
         shapes[f"{name}.weight"] = (latent_dims, flat)
         shapes[f"{name}.bias"] = (latent_dims,)
     shapes["fc_up.weight"] = (flat, latent_dims)
     shapes["fc_up.bias"] = (flat,)
-    for up, ci, co, ref, rci, rco in UNET_DEC:
+    for up, ci, co, ref, rci, rco in dec:
         shapes[f"{up}.weight"] = (ci, co, 2, 2)
         shapes[f"{up}.bias"] = (co,)
         block(ref, rci, rco)
@@ -716,12 +723,13 @@ def unet256_state_shapes(latent_dims=64, image_size=32):
     return shapes
 
 
-def construct_state_unet256(latent_dims=64, p_dropout=0.1, image_size=32):
-    """Restates VAEUnet256.__init__ (vae_original.py:78-119), consuming torch's global CPU generator in the same
-    order: the four encoder blocks, the train-mode dummy forward of _get_flattened_shape (:122-138; one Bernoulli
-    mask per block when p > 0, GroupNorm keeps no running state), fc_mu, fc_logvar, their xavier_uniform_(gain=0.1)
-    (:104-105), fc_up, then up / refine pairs and the head."""
-    shapes = unet256_state_shapes(latent_dims, image_size)
+def construct_state_unet(variant="256", latent_dims=64, p_dropout=0.1, image_size=32):
+    """Restates the constructors (vae_original.py:78-119, 295-340), consuming torch's global CPU generator in the same
+    order: the encoder blocks, the train-mode dummy forward of _get_flattened_shape (:122-138; one Bernoulli mask per
+    block when p > 0, GroupNorm keeps no running state), fc_mu, fc_logvar, for VAEUnet256 their
+    xavier_uniform_(gain=0.1) (:104-105), fc_up, then up / refine pairs and the head."""
+    enc, dec, xavier, _ = UNET_VARIANTS[variant]
+    shapes = unet_state_shapes(variant, latent_dims, image_size)
     sd = OrderedDict()
 
     def conv_like(wname, bname):
@@ -738,47 +746,63 @@ def construct_state_unet256(latent_dims=64, p_dropout=0.1, image_size=32):
             sd[f"{name}.double_conv.{j + 1}.weight"] = torch.ones(c)
             sd[f"{name}.double_conv.{j + 1}.bias"] = torch.zeros(c)
 
-    for name, _, _ in UNET_ENC:
+    for name, _, _ in enc:
         block(name)
     if p_dropout > 0:
         s = image_size
-        for i, (name, _, co) in enumerate(UNET_ENC):
+        for i, (name, _, co) in enumerate(enc):
             F.dropout(torch.zeros(1, co, s, s), p_dropout, True)      # the dummy forward's mask draw
-            if i < 3:
+            if i < len(enc) - 1:
                 s //= 2
     for name in ("fc_mu", "fc_logvar"):
         conv_like(f"{name}.weight", f"{name}.bias")
-    for name in ("fc_mu", "fc_logvar"):
-        shp = shapes[f"{name}.weight"]
-        sd[f"{name}.weight"] = _uniform(shp, 0.1 * math.sqrt(6.0 / (shp[0] + shp[1])))
+    if xavier:
+        for name in ("fc_mu", "fc_logvar"):
+            shp = shapes[f"{name}.weight"]
+            sd[f"{name}.weight"] = _uniform(shp, 0.1 * math.sqrt(6.0 / (shp[0] + shp[1])))
     conv_like("fc_up.weight", "fc_up.bias")
-    for up, _, _, ref, _, _ in UNET_DEC:
+    for up, _, _, ref, _, _ in dec:
         conv_like(f"{up}.weight", f"{up}.bias")
         block(ref)
     conv_like("head.weight", "head.bias")
     return OrderedDict((k, sd[k]) for k in shapes)
 
 
-def unet256_forward(x, sd, eps, train=True, p_dropout=0.0, masks=None):
-    """VAEUnet256.forward (vae_original.py:141-175) with eps injected -> (logits, mu, logvar).
-    masks: optional dict block name -> dropout keep mask (7 blocks)."""
+def unet_forward(variant, x, sd, eps, train=True, p_dropout=0.0, masks=None):
+    """VAEUnet256.forward (vae_original.py:141-175) / VAEUnet1024.forward (:370-403) with eps injected
+    -> (logits, mu, logvar).  masks: optional dict block name -> dropout keep mask."""
+    enc, dec, _, clamp = UNET_VARIANTS[variant]
     masks = masks or {}
     skips = []
-    for i, (name, _, _) in enumerate(UNET_ENC):
+    for i, (name, _, _) in enumerate(enc):
         x = double_conv_gn(x, sd, name, train, p_dropout, masks.get(name))
-        if i < 3:
+        if i < len(enc) - 1:
             skips.append(x)
             x = F.max_pool2d(x, 2)
     n, c, h, w = x.shape
     m = x.reshape(n, c * h * w)
     mu = F.linear(m, sd["fc_mu.weight"], sd["fc_mu.bias"])
     logvar = F.linear(m, sd["fc_logvar.weight"], sd["fc_logvar.bias"])
+    if clamp is not None:
+        logvar = torch.clamp(logvar, min=clamp[0], max=clamp[1])
     z = reparameterize(mu, logvar, eps)
     x = torch.tanh(F.linear(z, sd["fc_up.weight"], sd["fc_up.bias"])).view(n, c, h, w)
-    for up, _, _, ref, _, _ in UNET_DEC:
+    for up, _, _, ref, _, _ in dec:
         u = F.conv_transpose2d(x, sd[f"{up}.weight"], sd[f"{up}.bias"], stride=2)
         x = double_conv_gn(torch.cat([u, skips.pop()], dim=1), sd, ref, train, p_dropout, masks.get(ref))
     return F.conv2d(x, sd["head.weight"], sd["head.bias"]), mu, logvar
+
+
+def unet256_state_shapes(latent_dims=64, image_size=32):
+    return unet_state_shapes("256", latent_dims, image_size)
+
+
+def construct_state_unet256(latent_dims=64, p_dropout=0.1, image_size=32):
+    return construct_state_unet("256", latent_dims, p_dropout, image_size)
+
+
+def unet256_forward(x, sd, eps, train=True, p_dropout=0.0, masks=None):
+    return unet_forward("256", x, sd, eps, train, p_dropout, masks)
 
 
 def unet_loss_mse(x, x_hat, mu, logvar, kl_weight):

@@ -73,19 +73,35 @@ def test_upconv_node_against_autograd(n, H, W, Ci, Co):
     assert rel_l2(up.bias.grad.cpu(), gb) <= 1e-5
 
 
+def test_clamp_f32(L):
+    g = torch.Generator().manual_seed(2)
+    x = (4 * torch.randn(1000, generator=g)).requires_grad_(True)
+    x.data[:4] = torch.tensor([-5.0, 5.0, -5.0001, 5.0001])           # the bounds themselves pass the gradient
+    ref = torch.clamp(x, min=-5, max=5)
+    go = torch.randn(1000, generator=g)
+    ref.backward(go)
+    xd, gd = x.detach().to(DEV), go.to(DEV)
+    out = torch.full((1000,), float("nan"), device=DEV)
+    L.call("vae_clamp_f32", L.ptr(xd), None, -5.0, 5.0, L.ptr(out), 1000, L.current_stream())
+    assert torch.equal(out.cpu(), ref.detach())
+    L.call("vae_clamp_f32", L.ptr(xd), L.ptr(gd), -5.0, 5.0, L.ptr(out), 1000, L.current_stream())
+    assert torch.equal(out.cpu(), x.grad)
+
+
 def cosine(a, b):
     a, b = a.double().reshape(-1), b.double().reshape(-1)
     return float((a @ b) / (a.norm() * b.norm()).clamp_min(1e-300))
 
 
-@pytest.mark.parametrize("name", ["unet256_s16", "unet256_s32_nodrop"])
+@pytest.mark.parametrize("name", ["unet256_s16", "unet256_s32_nodrop", "unet1024_s32"])
 def test_unet_against_reference_fixture(name):
-    from vae_amd.unet import VAEUnet256, vae_loss_mse
+    from vae_amd import unet
+    from vae_amd.unet import vae_loss_mse
     c = UnetCase(name)
     torch.manual_seed(c.seed)
-    m = VAEUnet256(3, c.latent, c.p, c.size)
+    m = getattr(unet, "VAEUnet" + c.variant)(3, c.latent, c.p, c.size)
     torch.manual_seed(c.seed)
-    init = O.construct_state_unet256(c.latent, c.p, c.size)
+    init = O.construct_state_unet(c.variant, c.latent, c.p, c.size)
     msd = m.state_dict()
     assert list(msd.keys()) == list(init.keys())
     assert all(torch.equal(msd[k], init[k]) for k in init)          # same seed, same initial weights as the reference
@@ -104,7 +120,7 @@ def test_unet_against_reference_fixture(name):
     loss.backward()
     # gradients against the oracle (fp32, same masks and eps): direction and size
     leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    o_out, o_mu, o_lv = O.unet256_forward(x, leaf, eps, True, c.p, masks)
+    o_out, o_mu, o_lv = O.unet_forward(c.variant, x, leaf, eps, True, c.p, masks)
     O.unet_loss_mse(x, o_out, o_mu, o_lv, c.kl_weight).backward()
     worst = 1.0
     tot_dot = tot_a = tot_b = 0.0
@@ -130,7 +146,7 @@ def test_unet_trains_with_philox_streams():
 
     def rewind(step):
         m.rng_step = step
-        for n_ in m.ENC + tuple(r for _, r in m.DEC):
+        for n_ in m.block_names():
             getattr(m, n_).rng_step = step
     rewind(5)
     a = [t.detach().clone() for t in m(x)]

@@ -62,6 +62,7 @@ SIGNATURES = {
     "vae_conv1x1_out_fwd": (None, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "vae_conv1x1_out_bwd_blocks": (c_int, [c_int, c_int, c_int]),
     "vae_conv1x1_out_bwd": (None, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "vae_clamp_f32": (None, [P, P, c_float, c_float, P, c_long, P]),
     "vae_maxpool2_fwd": (None, [P, P, P, c_int, c_int, c_int, c_int, P]),
     "vae_maxpool2_bwd": (None, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "vae_gn_act_fwd": (None, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_double, P, c_ulonglong,

@@ -121,6 +121,16 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restri
     }
 }
 
+// torch.clamp(x, lo, hi) and its backward on fp32 (the deeper U-Net draft clamps logvar, vae/practice/vae_original.py:390):
+// g == null: out = min(max(x, lo), hi);  g != null: out = g where lo <= x <= hi, else 0
+__global__ __launch_bounds__(256) void clamp_f32_kernel(const float* __restrict__ x, const float* __restrict__ g, float lo,
+                                                        float hi, float* __restrict__ out, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float v = x[i];
+        out[i] = g ? ((v >= lo && v <= hi) ? g[i] : 0.f) : fminf(fmaxf(v, lo), hi);
+    }
+}
+
 static int pool_grid(long items) {
     long b = (items + 255) / 256;
     if (b < 1) b = 1;
@@ -183,4 +193,13 @@ extern "C" int vae_colsum_bf16(const void* x, long rows, int C, float* partial, 
         VAE_LAUNCH_CHECK("colsum_bf16_kernel");
     }
     return vae_sum_partials(partial, nb, C, out, 1.0f, stream);
+}
+
+extern "C" int vae_clamp_f32(const float* x, const float* g, float lo, float hi, float* out, long n, void* stream) {
+    VAE_CHECK(x && out && n > 0 && lo <= hi, "vae_clamp_f32: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof("clamp_f32_kernel", 0.0, (g ? 12.0 : 8.0) * n, s);
+    hipLaunchKernelGGL(clamp_f32_kernel, dim3(pool_grid(n)), dim3(256), 0, s, x, g, lo, hi, out, n);
+    VAE_LAUNCH_CHECK("clamp_f32_kernel");
+    return 0;
 }

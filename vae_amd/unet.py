@@ -1,4 +1,5 @@
-"""The drafts' U-Net VAE (vae/practice/vae_original.py:77-181, class VAEUnet256) over the C-ABI kernels.
+"""The drafts' U-Net VAEs (vae/practice/vae_original.py:77-181 class VAEUnet256, :184-403 class VAEUnet1024) over the
+C-ABI kernels.
 
 Encoder: three GroupNorm double-conv blocks whose UNPOOLED outputs stay as skip tensors + MaxPool2d(2), a middle block,
 fc_mu / fc_logvar; decoder: tanh(fc_up), three times ConvTranspose2d(k2, s2) -> cat([up, skip]) -> double conv; a 1x1
@@ -234,93 +235,147 @@ class UpConvT2x2(nn.ConvTranspose2d):
         return self.forward_nhwc(x.permute(0, 2, 3, 1).to(torch.bfloat16)).permute(0, 3, 1, 2).float()
 
 
-class VAEUnet256(nn.Module):
-    """Drop-in for the drafts' ``VAEUnet256(in_channels, latent_dims, p_dropout, image_size)``
-    (vae/practice/vae_original.py:77-181): same constructor (consuming torch's RNG in the same order, so the same seed
-    gives the same initial weights), same state_dict, ``forward(x) -> (logits, mu, logvar)``.
-    ``eps`` / ``keep_masks`` (dict block name -> uint8 NCHW keep flags) replace the Philox draws for parity tests."""
+class _Clamp(torch.autograd.Function):
+    """torch.clamp(x, lo, hi) on fp32 (vae_original.py:390); the gradient passes where lo <= x <= hi."""
 
-    ENC = ("conv0", "conv1", "conv2", "middle")
-    DEC = (("up2", "refine2"), ("up1", "refine1"), ("up0", "refine0"))
+    @staticmethod
+    def forward(ctx, x, lo, hi):
+        x = x.contiguous()
+        out = torch.empty_like(x)
+        _lib.call("vae_clamp_f32", x.data_ptr(), None, lo, hi, out.data_ptr(), x.numel(), _lib.current_stream())
+        ctx.save_for_backward(x)
+        ctx.lim = (lo, hi)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        g = g.float().contiguous()
+        dx = torch.empty_like(x)
+        _lib.call("vae_clamp_f32", x.data_ptr(), g.data_ptr(), ctx.lim[0], ctx.lim[1], dx.data_ptr(), x.numel(),
+                  _lib.current_stream())
+        return dx, None, None
+
+
+class _UnetVAE(nn.Module):
+    """The two U-Net VAEs of the draft script share this body; a subclass gives the channel plan.
+
+    ENC: (name, in, out) of the encoder blocks, the last one being ``middle`` (a MaxPool2d(2) behind every other one);
+    DEC: (up name, up in, up out, refine name, refine in, refine out); XAVIER: xavier_uniform_(gain=0.1) on the latent
+    heads; LOGVAR_CLAMP: clamp applied to logvar before it is used and returned, or None."""
+
+    ENC = ()
+    DEC = ()
+    XAVIER = False
+    LOGVAR_CLAMP = None
 
     def __init__(self, in_channels, latent_dims, p_dropout, image_size):
         super().__init__()
-        if image_size % 8 or latent_dims % 64:
-            raise ValueError("VAEUnet256: image_size must be a multiple of 8 and latent_dims a multiple of 64")
+        down = 1 << (len(self.ENC) - 1)
+        if image_size % down or latent_dims % 64:
+            raise ValueError(f"{type(self).__name__}: image_size must be a multiple of {down} and latent_dims a multiple of 64")
         self.image_size = image_size
-        self.conv0 = DoubleConvGN(3, 64, p_dropout)              # 3 input channels whatever in_channels says (:88)
-        self.pool0 = nn.MaxPool2d(2)
-        self.conv1 = DoubleConvGN(64, 128, p_dropout)
-        self.pool1 = nn.MaxPool2d(2)
-        self.conv2 = DoubleConvGN(128, 256, p_dropout)
-        self.pool2 = nn.MaxPool2d(2)
-        self.middle = DoubleConvGN(256, 256, p_dropout)
+        for i, (name, ci, co) in enumerate(self.ENC):
+            setattr(self, name, DoubleConvGN(ci, co, p_dropout))          # conv0 takes 3 channels whatever in_channels says
+            if i < len(self.ENC) - 1:
+                setattr(self, f"pool{i}", nn.MaxPool2d(2))
         C, H, W = self._get_flattened_shape(in_channels, p_dropout)
         self.chw = (C, H, W)
         self.flattened_dim = C * H * W
         self.fc_mu = nn.Linear(self.flattened_dim, latent_dims)
         self.fc_logvar = nn.Linear(self.flattened_dim, latent_dims)
-        nn.init.xavier_uniform_(self.fc_mu.weight, gain=0.1)
-        nn.init.xavier_uniform_(self.fc_logvar.weight, gain=0.1)
+        if self.XAVIER:
+            nn.init.xavier_uniform_(self.fc_mu.weight, gain=0.1)
+            nn.init.xavier_uniform_(self.fc_logvar.weight, gain=0.1)
         self.fc_up = nn.Linear(latent_dims, C * W * H)
-        self.up2 = UpConvT2x2(256, 128)
-        self.refine2 = DoubleConvGN(128 + 256, 128, p_dropout)
-        self.up1 = UpConvT2x2(128, 64)
-        self.refine1 = DoubleConvGN(64 + 128, 64, p_dropout)
-        self.up0 = UpConvT2x2(64, 64)
-        self.refine0 = DoubleConvGN(64 + 64, 64, p_dropout)
+        for up, uci, uco, ref, rci, rco in self.DEC:
+            setattr(self, up, UpConvT2x2(uci, uco))
+            setattr(self, ref, DoubleConvGN(rci, rco, p_dropout))
         self.head = nn.Conv2d(64, 3, 1, padding=0, stride=1)
         # one dropout stream per block; stream 4 is the eps stream of the reparameterisation kernel
-        for sid, name in zip((0, 1, 2, 3, 5, 6, 7), self.ENC + tuple(r for _, r in self.DEC)):
-            getattr(self, name).stream_id = sid
+        for sid, name in enumerate(self.block_names()):
+            getattr(self, name).stream_id = sid if sid < 4 else sid + 1
         self.rng_seed, self.rng_step, self.rank = 1337, 0, 0
 
+    @classmethod
+    def block_names(cls):
+        return tuple(e[0] for e in cls.ENC) + tuple(d[3] for d in cls.DEC)
+
     def _get_flattened_shape(self, in_channels, p_dropout):
-        """the reference pushes zeros(1, C, S, S) through the encoder in train mode (:122-138): the only lasting effect
-        is one Bernoulli mask drawn per block from the global generator when p > 0 (GroupNorm keeps no running
-        state) -- drawn here on the same shapes so that later initialisations see the same generator state."""
+        """the reference pushes zeros(1, C, S, S) through the encoder in train mode (vae_original.py:122-138,343-362):
+        the only lasting effect is one Bernoulli mask drawn per block from the global generator when p > 0 (GroupNorm
+        keeps no running state) -- drawn here on the same shapes so that later initialisations see the same generator
+        state."""
         s = self.image_size
-        if p_dropout > 0:
-            for i, c in enumerate((64, 128, 256, 256)):
-                F.dropout(torch.zeros(1, c, s >> min(i, 3), s >> min(i, 3)), p_dropout, True)
-        return 256, s // 8, s // 8
+        for i, (_, _, co) in enumerate(self.ENC):
+            if p_dropout > 0:
+                F.dropout(torch.zeros(1, co, s, s), p_dropout, True)
+            if i < len(self.ENC) - 1:
+                s //= 2
+        return self.ENC[-1][2], s, s
 
     def forward(self, x, eps=None, keep_masks=None):
         if not x.is_cuda:
-            raise RuntimeError("VAEUnet256 runs on the GPU only (no CPU fallback)")
+            raise RuntimeError(f"{type(self).__name__} runs on the GPU only (no CPU fallback)")
         _lib.load()
         km = {}
         for k, v in (keep_masks or {}).items():
             km[k] = v.permute(0, 2, 3, 1).contiguous().to(torch.uint8)
-        for name in self.ENC + tuple(r for _, r in self.DEC):
+        for name in self.block_names():
             blk = getattr(self, name)
             blk.rng_seed, blk.rank = self.rng_seed, self.rank
         skips = []
         h = x
-        for i, name in enumerate(self.ENC):
+        for i, (name, _, _) in enumerate(self.ENC):
             h = getattr(self, name).forward_nhwc(h, keep_mask=km.get(name))
-            if i < 3:
+            if i < len(self.ENC) - 1:
                 skips.append(h)
                 h = maxpool2_nhwc(h)
         n, hh, ww, C = h.shape
         mu, logvar = _LatentHeads.apply(h.reshape(n, hh * ww * C), self.fc_mu.weight, self.fc_mu.bias,
                                         self.fc_logvar.weight, self.fc_logvar.bias, hh * ww, C)
+        if self.LOGVAR_CLAMP is not None:
+            logvar = _Clamp.apply(logvar, float(self.LOGVAR_CLAMP[0]), float(self.LOGVAR_CLAMP[1]))
         z = self.reparameterize(mu, logvar, eps)
         h = _FcUpTanh.apply(z, self.fc_up.weight, self.fc_up.bias, hh * ww, C).view(n, hh, ww, C)
-        for up, ref in self.DEC:
+        for up, _, _, ref, _, _ in self.DEC:
             u = getattr(self, up).forward_nhwc(h)
             h = getattr(self, ref).forward_nhwc(torch.cat([u, skips.pop()], dim=-1), keep_mask=km.get(ref))
         out = _Conv1x1Out.apply(h, self.head.weight, self.head.bias)
         return out, mu, logvar
 
     def reparameterize(self, mu, logvar, eps=None):
-        """reference signature (:178-181) -> z (bf16, the decoder's operand type)."""
+        """reference signature (vae_original.py:178-181) -> z (bf16, the decoder's operand type)."""
         step = self.rng_step
         if eps is None:
             self.rng_step += 1
         else:
             eps = eps.float().contiguous()
         return _Reparam.apply(mu, logvar, eps, (self.rng_seed, step, self.rank))
+
+
+class VAEUnet256(_UnetVAE):
+    """Drop-in for the drafts' ``VAEUnet256(in_channels, latent_dims, p_dropout, image_size)``
+    (vae/practice/vae_original.py:77-181): same constructor (consuming torch's RNG in the same order, so the same seed
+    gives the same initial weights), same state_dict, ``forward(x) -> (logits, mu, logvar)``.
+    ``eps`` / ``keep_masks`` (dict block name -> uint8 NCHW keep flags) replace the Philox draws for parity tests."""
+
+    ENC = (("conv0", 3, 64), ("conv1", 64, 128), ("conv2", 128, 256), ("middle", 256, 256))
+    DEC = (("up2", 256, 128, "refine2", 128 + 256, 128), ("up1", 128, 64, "refine1", 64 + 128, 64),
+           ("up0", 64, 64, "refine0", 64 + 64, 64))
+    XAVIER = True
+
+
+class VAEUnet1024(_UnetVAE):
+    """Drop-in for the drafts' ``VAEUnet1024`` (vae/practice/vae_original.py:184-403; of its two ``__init__`` bodies the
+    second, :295-340, is the one Python keeps): five levels up to 1024 channels, default initialisation of the latent
+    heads, and logvar clamped to [-5, 5] before use and return (:390; the [-10, 10] clamp inside its ``reparameterize``,
+    :365, then never binds)."""
+
+    ENC = (("conv0", 3, 64), ("conv1", 64, 128), ("conv2", 128, 256), ("conv3", 256, 512), ("middle", 512, 1024))
+    DEC = (("up3", 1024, 512, "refine3", 1024, 512), ("up2", 512, 256, "refine2", 512, 256),
+           ("up1", 256, 128, "refine1", 256, 128), ("up0", 128, 64, "refine0", 128, 64))
+    LOGVAR_CLAMP = (-5.0, 5.0)
 
 
 def vae_loss_mse(x, x_hat, mu, logvar, kl_weight):
