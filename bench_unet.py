@@ -1,8 +1,8 @@
-"""Throughput of the drafts' U-Net VAE (vae_amd.unet.VAEUnet256; reference vae/practice/vae_original.py:77-181) on
+"""Throughput of the drafts' U-Net VAE (vae_amd.unet.VAEUnet256 / VAEUnet1024; reference vae/practice/vae_original.py:77-403) on
 one MI355X: full training step (forward, MSE + KL loss, backward through the autograd nodes, clip_grad_norm_, AdamW)
 on synthetic data resident in HBM.  A side measurement next to bench.py (which measures the headline VAEConv path).
 
-    python bench_unet.py [--size 32] [--batch 512] [--latent 128] [--steps 30] [--warmup 5]
+    python bench_unet.py [--model 256|1024] [--size 32] [--batch 512] [--latent 128] [--steps 30] [--warmup 5]
 """
 import argparse
 import json
@@ -18,14 +18,16 @@ def main():
     ap.add_argument("--latent", type=int, default=128)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--model", default="256", choices=["256", "1024"], help="VAEUnet256 or VAEUnet1024")
     ap.add_argument("--kernels", action="store_true", help="per-kernel event times from the library's profiler")
     a = ap.parse_args()
     from vae_amd import _lib
-    from vae_amd.unet import VAEUnet256, vae_loss_mse
+    from vae_amd import unet
+    from vae_amd.unet import vae_loss_mse
     _lib.load()
     dev = torch.device("cuda", 0)
     torch.manual_seed(1337)
-    m = VAEUnet256(3, a.latent, 0.1, a.size).to(dev).train()
+    m = getattr(unet, "VAEUnet" + a.model)(3, a.latent, 0.1, a.size).to(dev).train()
     opt = torch.optim.AdamW(m.parameters(), lr=1e-4, fused=True)
     xs = [torch.rand(a.batch, 3, a.size, a.size, device=dev) for _ in range(4)]
 
@@ -46,7 +48,7 @@ def main():
         loss = step(xs[i % 4])
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    out = {"model": f"VAEUnet256(3,{a.latent},0.1,{a.size})", "batch": a.batch, "steps": a.steps,
+    out = {"model": f"VAEUnet{a.model}(3,{a.latent},0.1,{a.size})", "batch": a.batch, "steps": a.steps,
            "ms_per_step": 1e3 * el / a.steps, "images_per_s": a.batch * a.steps / el, "final_loss": loss.item(),
            "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30}
     if a.kernels:
