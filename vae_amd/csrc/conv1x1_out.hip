@@ -72,15 +72,14 @@ __global__ __launch_bounds__(256) void conv1x1_out_bwd_kernel(const float* __res
         float dl[CO], v[8], o8[8];
 #pragma unroll
         for (int o = 0; o < CO; ++o) dl[o] = g[(img * CO + o) * hw + p];
-        const bool want_x = x != nullptr;
-        if (want_x) load8(x + pix * 64 + c0, v);
+        load8(x + pix * 64 + c0, v);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             float d = 0.f;
 #pragma unroll
             for (int o = 0; o < CO; ++o) {
                 d += dl[o] * wv[o][i];
-                if (want_x) a_w[o][i] += dl[o] * v[i];
+                a_w[o][i] += dl[o] * v[i];
             }
             o8[i] = d;
         }
