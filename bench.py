@@ -23,7 +23,10 @@ import os
 import sys
 import time
 
-import torch
+# RCCL shares device memory between the ranks through dmabuf handles; the legacy IPC mode fails on this driver
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
