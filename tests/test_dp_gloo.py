@@ -54,15 +54,19 @@ def _worker(rank, port, outdir):
         torch.set_num_threads(2)
         # ---- 1. plain reducer semantics on a synthetic buffer
         total = 1000
-        g = torch.arange(total, dtype=torch.float32) * (rank + 1)
-        red = dp.BucketedReducer(g, [(600, 1000), (250, 600), (0, 250)], bucket_bytes=4 * 128)
-        assert [len(b) for b in red.buckets] == [4, 3, 2]
-        for s in range(3):
-            red.stage_done(s)
-        red.wait()
-        expect = torch.arange(total, dtype=torch.float32) * 1.5
-        assert torch.equal(g, expect)
-        assert red.handles == []
+        # one exchange per stage (default), and the first stage's range riding with the second's
+        for merge, counts in ((False, [4, 3, 2]), (True, [0, 6, 2])):
+            g = torch.arange(total, dtype=torch.float32) * (rank + 1)
+            red = dp.BucketedReducer(g, [(600, 1000), (250, 600), (0, 250)], bucket_bytes=4 * 128, merge_first=merge)
+            assert [len(b) for b in red.buckets] == counts
+            for s in range(3):
+                red.stage_done(s)
+                if merge and s == 0:
+                    assert red.handles == []
+            red.wait()
+            expect = torch.arange(total, dtype=torch.float32) * 1.5
+            assert torch.equal(g, expect)
+            assert red.handles == []
 
         # ---- 2. a data-parallel step with the oracle's arithmetic
         shapes = O.state_shapes(3, 3, 8, 16)

@@ -33,15 +33,15 @@ def test_reducer_over_rccl_is_the_identity_at_world_size_one():
         conf = Config(kl_weight=1.0, percep_weight=0.0, recon_loss="l1", lr=1e-4)
         xs = [torch.rand(128, 3, 32, 32, device="cuda", generator=torch.Generator(device="cuda").manual_seed(i)) for i in range(3)]
 
-        def run(with_reducer, side_stream=False):
+        def run(with_reducer, side_stream=False, merge_first=False):
             torch.manual_seed(1337)
             m = VAEConv(3, 3, 128, 0.1, 32).cuda().train()
             m.rng_seed, m.rank = 1337, 0
             red = None
             if with_reducer:
                 red = BucketedReducer(m.flat_grads, stage_ranges(m._offsets, m.flat_grads.numel()), bucket_bytes=2 << 20,
-                                      side_stream=side_stream)
-                assert red.avg_op and sum(len(b) for b in red.buckets) >= 6
+                                      side_stream=side_stream, merge_first=merge_first)
+                assert red.avg_op and sum(len(b) for b in red.buckets) >= 6 and bool(red.buckets[0]) != merge_first
                 red.world = 2          # force the exchange although there is nobody to exchange with
             fs = FusedStep(m, FlatAdamW(m, lr=1e-4), conf, red)
             losses = torch.stack([fs(xs[i % 3]).clone() for i in range(12)])
@@ -50,8 +50,9 @@ def test_reducer_over_rccl_is_the_identity_at_world_size_one():
 
         la, pa = run(False)
         assert torch.isfinite(la).all()
-        for side_stream in (False, True):          # issued from the compute stream (default) or from a stream of its own
-            lb, pb = run(True, side_stream)
-            assert torch.equal(la, lb) and torch.equal(pa, pb), side_stream
+        # issued from the compute stream (default) or from a stream of its own; first stage exchanged alone or with the second
+        for side_stream, merge_first in ((False, False), (True, False), (False, True)):
+            lb, pb = run(True, side_stream, merge_first)
+            assert torch.equal(la, lb) and torch.equal(pa, pb), (side_stream, merge_first)
     finally:
         dist.destroy_process_group()

@@ -28,14 +28,16 @@ def main():
     conf = Config(kl_weight=1.0, percep_weight=0.0, recon_loss="l1", lr=1e-4)
     xs = [torch.rand(a.batch, 3, 32, 32, device="cuda") for _ in range(8)]
     out = {"batch": a.batch, "steps": a.steps}
-    for mode in ("plain", "staged_no_exchange", "exchange_16MB", "exchange_one_bucket_per_stage", "exchange_from_main_stream"):
+    for mode in ("plain", "staged_no_exchange", "exchange_16MB", "exchange_one_bucket_per_stage", "exchange_from_main_stream",
+                 "exchange_main_stream_two_collectives"):
         torch.manual_seed(1337)
         m = VAEConv(3, 3, 128, 0.1, 32).cuda().train()
         red = None
         if mode != "plain":
             red = BucketedReducer(m.flat_grads, stage_ranges(m._offsets, m.flat_grads.numel()),
                                   bucket_bytes=(1 << 30) if mode.endswith("per_stage") else (16 << 20),
-                                  side_stream=not mode.endswith("main_stream"))
+                                  side_stream=not (mode.endswith("main_stream") or mode.endswith("two_collectives")),
+                                  merge_first=mode.endswith("two_collectives"))
             if mode.startswith("exchange"):
                 red.world = 2
         fs = FusedStep(m, FlatAdamW(m, lr=1e-4), conf, red)

@@ -38,10 +38,16 @@ class BucketedReducer:
     """all-reduce (mean) of `flat_grads` in per-stage buckets."""
 
     def __init__(self, flat_grads: torch.Tensor, ranges: Sequence[Tuple[int, int]], bucket_bytes: int = 16 << 20,
-                 group=None, side_stream: bool = False):
+                 group=None, side_stream: bool = False, merge_first: bool = False):
         self.flat = flat_grads
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        ranges = [tuple(r) for r in ranges]
+        # merge_first: the first stage's range is exchanged together with the second's when the two are adjacent in
+        # the flat buffer (one collective fewer per step; it then runs under the last stage instead of the second).
+        # On one rank it measures the same as three collectives, so it is off unless asked for.
+        if merge_first and len(ranges) >= 3 and ranges[1][1] == ranges[0][0]:
+            ranges = [(0, 0), (ranges[1][0], ranges[0][1])] + ranges[2:]
         self.buckets = [split_buckets(a, b, max(1, bucket_bytes // flat_grads.element_size())) for a, b in ranges]
         self.cuda = flat_grads.is_cuda
         # torch's NCCL process group runs a collective on its own stream, ordered after the stream it was issued from;
@@ -53,7 +59,7 @@ class BucketedReducer:
 
     def stage_done(self, stage: int):
         """call right after the kernels of backward stage `stage` were enqueued."""
-        if self.world == 1:
+        if self.world == 1 or not self.buckets[stage]:
             return
         op = dist.ReduceOp.AVG if self.avg_op else dist.ReduceOp.SUM
         if self.cuda and self.comm_stream is not None:
