@@ -3,6 +3,10 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2_1gpu]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Started plainly with --gpus N > 1 (no WORLD_SIZE in the environment) the process makes no GPU call: it starts
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child, one rank per GPU, passes rank 0's
+JSON line through and exits with the child's status.
+
 A step is one full train step on one synthetic batch already resident in HBM: forward,
 ELBO loss (+ its gradient), backward, global-norm clip, AdamW, bf16 weight repack -- the
 reference's loop body (vae/training/train.py:327-339) -- at BASELINE config 2
@@ -50,6 +54,31 @@ def train_flops_per_image(in_ch, latent, S):
     return 6 * macs - 2 * first
 
 
+def family(name):
+    """kernel family = the name without its template arguments (conv3_patch_tn_kernel<64> and <128> are one family)."""
+    return name.split("<")[0]
+
+
+def by_family(kernels):
+    """fold the per-kernel rows of profile_pass into one row per family, largest share of the step first."""
+    fam = {}
+    for r in kernels:
+        f = fam.setdefault(family(r["kernel"]), {"kernel": family(r["kernel"]), "bound": r["bound"], "ms_per_step": 0.0,
+                                                 "launches_per_step": 0.0, "work": 0.0, "peak": r["peak"], "unit": r["unit"]})
+        f["ms_per_step"] += r["ms_per_step"]
+        f["launches_per_step"] += r["launches_per_step"]
+        f["work"] += r["achieved"] * r["ms_per_step"]          # (flop or byte rate) x time = work per step
+    out = []
+    for f in fam.values():
+        f["achieved"] = f["work"] / f["ms_per_step"] if f["ms_per_step"] > 0 else 0.0
+        f["frac"] = f["achieved"] / f["peak"]
+        f["avg_us"] = 1e3 * f["ms_per_step"] / max(f["launches_per_step"], 1e-9)
+        del f["work"]
+        out.append(f)
+    out.sort(key=lambda r: -r["ms_per_step"])
+    return out
+
+
 def profile_pass(step_fn, batches, nsteps=3):
     """instrumented pass: per-kernel HIP-event timings aggregated by the library."""
     from vae_amd import _lib
@@ -85,13 +114,16 @@ def pmc_traffic(kernel, config):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE are
     collected in separate profiler runs of this script and folded by tools_pmc_traffic.py; they cannot be
     read from inside the timed process).  None when no measurement of this workload's kernel is on file."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if config != "cfg2_1gpu" or not os.path.exists(path):
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if config != "cfg2_1gpu" or not paths:
         return None
     try:
-        with open(path) as f:
-            rec = json.load(f)["kernels"].get(kernel)
-        return rec["hbm_bytes_per_launch"] if rec else None
+        with open(paths[-1]) as f:                 # the latest round's measurement
+            ks = json.load(f)["kernels"]
+        rows = [v for k, v in ks.items() if family(k) == family(kernel)]
+        n = sum(r.get("launches", 1) for r in rows)
+        return sum(r["hbm_bytes_per_launch"] * r.get("launches", 1) for r in rows) / n if n else None
     except (OSError, ValueError, KeyError):
         return None
 
@@ -162,6 +194,19 @@ def bench_decode(args, model, conf, batch, Lat, S, world, rank, dev):
         dist.destroy_process_group()
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` typed as is: this process (which has made no GPU call and makes none) starts one
+    rank per GPU under torch.distributed.run as a child process and hands its exit status on."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--mode", choices=["train", "decode"], default="train")
@@ -177,7 +222,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--torch-optimizer", action="store_true", help="torch.optim.AdamW + clip_grad_norm_ instead of the fused kernel")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="form the process group, count the ranks with one all-reduce, print that and leave (touches no GPU "
+                         "with --backend gloo: checks the launcher path on a machine without one)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))
     if args.watchdog > 0:
         import faulthandler
         faulthandler.dump_traceback_later(args.watchdog, exit=True)
@@ -193,10 +243,22 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs one process per GPU: launch with "
-                             f"python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} "
-                             f"--master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks (WORLD_SIZE): they must agree")
+    if args.rendezvous_only:
+        if world > 1:
+            if args.backend == "nccl":
+                torch.cuda.set_device(local_rank)
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(args.backend)
+        one = torch.ones(1, device=torch.device("cuda", local_rank) if args.backend == "nccl" else "cpu")
+        if world > 1:
+            dist.all_reduce(one)
+        if rank == 0:
+            print(json.dumps({"rendezvous": "ok", "n_gpus": args.gpus, "n_ranks_seen": int(one.item()), "backend": args.backend}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
     if args.backend != "nccl":
         local_rank %= torch.cuda.device_count()      # a rehearsal: several ranks may share one card
     torch.cuda.set_device(local_rank)
@@ -229,15 +291,21 @@ def main():
     g = torch.Generator(device=dev).manual_seed(int(conf.seed) + rank)
     batches = [torch.rand(batch, Cin, S, S, device=dev, generator=g) for _ in range(8)]
 
+    n_ranks_seen = dist.get_world_size() if world > 1 else 1
     for i in range(args.warmup):
         step(batches[i % 8])
+    # one event after every step (on torch's current stream, the one every kernel of the step is launched on):
+    # the per-step durations behind the median; recording costs ~1 us of host time per step
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(args.steps):
         loss = step(batches[i % 8])
+        marks[i + 1].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -256,9 +324,12 @@ def main():
     if rank == 0:
         ips = world * batch * args.steps / elapsed
         fpi = train_flops_per_image(Cin, Lat, S)
+        per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
         out = {
             "metric": "training images/sec (whole node)", "value": ips, "unit": "images/s", "n_gpus": world,
+            "n_ranks_seen": n_ranks_seen,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_step_median": per_step[len(per_step) // 2], "ms_per_step_min": per_step[0],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{args.config}: VAEConv({Cin},3,{Lat},{float(conf.p_dropout)},{S}) full train step "
                                    f"(fwd + {conf.recon_loss}/KL loss + bwd + clip + AdamW), batch {batch} per GPU",
@@ -268,7 +339,9 @@ def main():
             "final_loss": final_loss,
         }
         if kernels:
-            top = kernels[0]
+            fams = by_family(kernels)
+            top = fams[0]                 # the kernel family with the largest share of the step
+            out["kernel_families"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in fams[:12]]
             out["roofline"] = {"kernel": top["kernel"], "bound": top["bound"], "achieved": top["achieved"],
                                "peak": top["peak"], "unit": top["unit"], "frac": top["frac"],
                                "traffic": pmc_traffic(top["kernel"], "" if args.batch else args.config),

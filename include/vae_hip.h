@@ -27,6 +27,8 @@ extern "C" {
 #define VAE_RECON_MSE 1         /* F.mse_loss(reduction="sum")                vae/practice/vae_conv.py:160-165 */
 #define VAE_RECON_BCE 2         /* F.binary_cross_entropy(reduction="sum")    vae/bak/vae_conv.py:183-190     */
 #define VAE_RECON_BCE_LOGITS 3  /* BCE-with-logits on clamp(x,-10,10)         vae/practice/vae_conv.py:146-151 */
+#define VAE_RECON_BCE_LOGITS_RAW 4 /* F.binary_cross_entropy_with_logits(reduction="sum") itself, no clamp: what
+                                    * vae_loss(..., loss=F.binary_cross_entropy_with_logits) computes, vae/training/train.py:46 */
 
 /* Philox stream ids: one per DoubleConv dropout (vae/models/vae.py:137) + eps (vae.py:110) */
 #define VAE_STREAM_DROPOUT0 0

@@ -272,7 +272,7 @@ def forward(x, sd, eps, train=True, p_dropout=0.0, masks=None, stats_out=None):
 # ----------------------------------------------------------------------------
 # Loss (vae/training/train.py:44-55 and the draft variants)
 # ----------------------------------------------------------------------------
-RECON_KINDS = ("l1", "mse", "bce", "bce_logits")
+RECON_KINDS = ("l1", "mse", "bce", "bce_logits", "bce_logits_raw")
 
 
 def recon_loss_sum(recon, target, kind: str):
@@ -282,6 +282,8 @@ def recon_loss_sum(recon, target, kind: str):
     bce : F.binary_cross_entropy (log clamped >= -100) vae/bak/vae_conv.py:183-190
     bce_logits : F.binary_cross_entropy_with_logits on logits clamped to
           [-10, 10]                                   vae/practice/vae_conv.py:146-151
+    bce_logits_raw : F.binary_cross_entropy_with_logits itself (no clamp), i.e. vae_loss called with
+          loss=F.binary_cross_entropy_with_logits     vae/training/train.py:46
     """
     if kind == "l1":
         return (recon - target).abs().sum()
@@ -295,6 +297,8 @@ def recon_loss_sum(recon, target, kind: str):
         xl = recon.clamp(-10.0, 10.0)
         # max(x,0) - x*t + log(1 + exp(-|x|))
         return (xl.clamp(min=0) - xl * target + torch.log1p(torch.exp(-xl.abs()))).sum()
+    if kind == "bce_logits_raw":
+        return (recon.clamp(min=0) - recon * target + torch.log1p(torch.exp(-recon.abs()))).sum()
     raise ValueError(kind)
 
 

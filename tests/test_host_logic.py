@@ -55,8 +55,9 @@ def test_linear_anneal_kl():
 
 def test_loss_kind_selection():
     assert train._kind_of(F.l1_loss) == 0 and train._kind_of(F.mse_loss) == 1
-    assert train._kind_of(F.binary_cross_entropy) == 2 and train._kind_of(F.binary_cross_entropy_with_logits) == 3
-    assert train._kind_of("bce") == 2
+    # the torch callable is the UNCLAMPED form (vae/training/train.py:46); the clamped draft form has its own name
+    assert train._kind_of(F.binary_cross_entropy) == 2 and train._kind_of(F.binary_cross_entropy_with_logits) == 4
+    assert train._kind_of("bce") == 2 and train._kind_of("bce_logits") == 3 and train._kind_of("bce_logits_raw") == 4
     with pytest.raises(ValueError):
         train._kind_of(F.smooth_l1_loss)
 
@@ -64,11 +65,23 @@ def test_loss_kind_selection():
 def test_loss_refuses_cpu_tensors_and_lpips():
     cfg = train.Config(kl_weight=1.0, percep_weight=0.0)
     x = torch.rand(2, 3, 8, 8)
-    with pytest.raises(RuntimeError, match="GPU only"):
+    with pytest.raises(RuntimeError, match="no CPU execution path"):
         train.l1_kl_percep_loss(x, x, torch.zeros(2, 4), torch.zeros(2, 4), cfg)
     cfg.percep_weight = 0.5
     with pytest.raises(NotImplementedError):
         train.vae_loss(x, x, torch.zeros(2, 4), torch.zeros(2, 4), F.l1_loss, lambda *a, **k: 0, cfg)
+    # the perceptual term is never silently dropped: every loss entry point refuses a non-zero weight,
+    # with or without an lpips_fn
+    with pytest.raises(NotImplementedError):
+        train.vae_loss(x, x, torch.zeros(2, 4), torch.zeros(2, 4), F.l1_loss, None, cfg)
+    with pytest.raises(NotImplementedError):
+        train.l1_kl_percep_loss(x, x, torch.zeros(2, 4), torch.zeros(2, 4), cfg)
+    with pytest.raises(NotImplementedError):
+        train.train_step(None, None, x, cfg)
+    with pytest.raises(NotImplementedError):
+        train.val_step(None, x, cfg)
+    with pytest.raises(NotImplementedError):
+        train.FusedStep(None, None, cfg)
 
 
 def test_stage_ranges_partition_the_flat_buffer():

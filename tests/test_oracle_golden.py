@@ -86,3 +86,29 @@ def test_train_steps():
         elif k.endswith("running_mean"):
             atol = steps * 1e-4 * 0.3
         check_digest(c, "final", k, v.float(), rtol=1e-5, atol_scale=atol)
+
+
+def test_recon_kinds_equal_the_torch_callables_the_reference_passes():
+    """vae_loss(..., loss=F.xxx) in the reference calls the torch functional with reduction="sum"
+    (vae/training/train.py:46); the oracle's closed forms must equal those calls, including logits beyond +-10
+    where the draft's clamped form (vae/practice/vae_conv.py:146-151) and the plain callable part ways."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(5)
+    t = torch.rand(4, 3, 8, 8, generator=g)
+    p = torch.rand(4, 3, 8, 8, generator=g) * 0.98 + 0.01
+    logits = torch.rand(4, 3, 8, 8, generator=g) * 40 - 20
+    for kind, fn, x in (("l1", F.l1_loss, p), ("mse", F.mse_loss, p), ("bce", F.binary_cross_entropy, p),
+                        ("bce_logits_raw", F.binary_cross_entropy_with_logits, logits)):
+        a = x.clone().requires_grad_(True)
+        b = x.clone().requires_grad_(True)
+        la, lb = O.recon_loss_sum(a, t, kind), fn(b, t, reduction="sum")
+        la.backward(); lb.backward()
+        assert abs(la.item() - lb.item()) <= 1e-5 * abs(lb.item()), kind
+        assert rel_l2(a.grad, b.grad) <= 1e-5, kind
+    a = logits.clone().requires_grad_(True)
+    b = logits.clone().requires_grad_(True)
+    la = O.recon_loss_sum(a, t, "bce_logits")
+    lb = F.binary_cross_entropy_with_logits(b.clamp(-10, 10), t, reduction="sum")
+    la.backward(); lb.backward()
+    assert abs(la.item() - lb.item()) <= 1e-5 * abs(lb.item()) and rel_l2(a.grad, b.grad) <= 1e-5
+    assert abs(la.item() - O.recon_loss_sum(logits, t, "bce_logits_raw").item()) > 1.0      # they do differ here

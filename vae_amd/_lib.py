@@ -145,6 +145,21 @@ def call(name, *args):
     return rc
 
 
-def current_stream():
+def current_stream(device=None):
+    """raw hipStream_t of torch's current stream (on `device`, default: the current device)."""
     import torch
-    return torch.cuda.current_stream().cuda_stream
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def check_device(t):
+    """The C entry points launch on the CURRENT device's stream and never switch devices (one process per GPU,
+    torch.cuda.set_device(local_rank) once): a tensor that lives on another GPU would be handed to the wrong
+    device's queue.  Raise instead."""
+    import torch
+    if not t.is_cuda:
+        raise RuntimeError("this path runs on an MI355X only (no CPU execution path): move the tensor to 'cuda'")
+    cur = torch.cuda.current_device()
+    if t.device.index != cur:
+        raise RuntimeError(f"tensor lives on cuda:{t.device.index} but the current device is cuda:{cur}: call "
+                           f"torch.cuda.set_device({t.device.index}) (one process per GPU) or wrap the call in "
+                           f"torch.cuda.device({t.device.index})")

@@ -5,7 +5,9 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -31,19 +33,25 @@ struct ProfRecord {
     const char* name;
     double flops, bytes;
 };
+// The profiler is one process-wide table behind a mutex; the only thing a launch reads when it is off is the
+// atomic flag.  It is a single-timeline tool: while it is armed, launches are expected from ONE host thread
+// (begin/end pairs of two threads would interleave in the table), which is how bench.py uses it.
+static std::mutex g_mu;
 static std::vector<hipEvent_t> g_ev;
 static std::vector<ProfRecord> g_rec;
-static bool g_on = false;
+static std::atomic<bool> g_on{false};
 static size_t g_cap = 0;
 
-bool prof_enabled() { return g_on; }
+bool prof_enabled() { return g_on.load(std::memory_order_acquire); }
 
 void prof_begin(const char* name, double flops, double bytes, hipStream_t s) {
+    std::lock_guard<std::mutex> lock(g_mu);
     if (!g_on || g_rec.size() >= g_cap) return;
     g_rec.push_back({name, flops, bytes});
     (void)hipEventRecord(g_ev[2 * (g_rec.size() - 1)], s);   // a failed record only loses this sample
 }
 void prof_end(hipStream_t s) {
+    std::lock_guard<std::mutex> lock(g_mu);
     if (!g_on || g_rec.empty() || g_rec.size() > g_cap) return;
     (void)hipEventRecord(g_ev[2 * (g_rec.size() - 1) + 1], s);
 }
@@ -58,6 +66,7 @@ extern "C" int vae_prof_start(int max_launches) {
         set_error("vae_prof_start: max_launches=%d out of range", max_launches);
         return 1;
     }
+    std::lock_guard<std::mutex> lock(g_mu);
     while (g_ev.size() < (size_t)2 * max_launches) {
         hipEvent_t e;
         if (hipEventCreate(&e) != hipSuccess) {
@@ -78,6 +87,7 @@ extern "C" int vae_prof_start(int max_launches) {
 extern "C" int vae_prof_stop(char* names, int* launches, double* total_ms, double* flops, double* bytes,
                              int max_rows) {
     using namespace vae;
+    std::lock_guard<std::mutex> lock(g_mu);
     g_on = false;
     if (hipDeviceSynchronize() != hipSuccess) {
         set_error("vae_prof_stop: hipDeviceSynchronize failed");

@@ -27,13 +27,19 @@ __device__ __forceinline__ void loss_elem(float r, float t, float gs, float& l, 
         l = -(t * lr + (1.f - t) * l1r);
         // d/dr = (r - t) / max(r (1 - r), 1e-12)   (ATen binary_cross_entropy_backward)
         g = (r - t) / fmaxf(r * (1.f - r), 1e-12f) * gs;
-    } else {
+    } else if (KIND == VAE_RECON_BCE_LOGITS) {
         // binary_cross_entropy_with_logits on logits clamped to [-10, 10]
         const float x = fminf(fmaxf(r, -10.f), 10.f);
         const float e = __expf(-fabsf(x));
         l = fmaxf(x, 0.f) - x * t + log1pf(e);
         const float sg = x >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
         g = (r >= -10.f && r <= 10.f) ? (sg - t) * gs : 0.f;   // clamp passes no gradient outside
+    } else {
+        // F.binary_cross_entropy_with_logits itself: max(x,0) - x t + log1p(exp(-|x|)), gradient sigmoid(x) - t
+        const float e = expf(-fabsf(r));
+        l = fmaxf(r, 0.f) - r * t + log1pf(e);
+        const float sg = r >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+        g = (sg - t) * gs;
     }
 }
 
@@ -130,7 +136,7 @@ extern "C" int vae_recon_loss_fwd_bwd(const float* recon, const float* target, f
                                       void* stream) {
     VAE_CHECK(recon && target && partial, "vae_recon_loss_fwd_bwd: null pointer");
     VAE_CHECK(n_elems > 0, "vae_recon_loss_fwd_bwd: n_elems must be > 0 (got %ld)", n_elems);
-    VAE_CHECK(kind >= 0 && kind <= 3, "vae_recon_loss_fwd_bwd: unknown kind %d", kind);
+    VAE_CHECK(kind >= 0 && kind <= 4, "vae_recon_loss_fwd_bwd: unknown kind %d", kind);
     VAE_CHECK(((uintptr_t)recon & 15) == 0 && ((uintptr_t)target & 15) == 0 &&
                   ((uintptr_t)grad & 15) == 0,
               "vae_recon_loss_fwd_bwd: pointers must be 16-byte aligned");
@@ -148,7 +154,8 @@ extern "C" int vae_recon_loss_fwd_bwd(const float* recon, const float* target, f
         case VAE_RECON_L1: LAUNCH(VAE_RECON_L1); break;
         case VAE_RECON_MSE: LAUNCH(VAE_RECON_MSE); break;
         case VAE_RECON_BCE: LAUNCH(VAE_RECON_BCE); break;
-        default: LAUNCH(VAE_RECON_BCE_LOGITS); break;
+        case VAE_RECON_BCE_LOGITS: LAUNCH(VAE_RECON_BCE_LOGITS); break;
+        default: LAUNCH(VAE_RECON_BCE_LOGITS_RAW); break;
     }
 #undef LAUNCH
     VAE_LAUNCH_CHECK("recon_loss_kernel");

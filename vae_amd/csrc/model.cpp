@@ -9,6 +9,8 @@
 #include <hip/hip_runtime.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "../../include/vae_hip.h"
 
 namespace vae {
@@ -473,11 +475,16 @@ struct Fork {
 };
 
 static const int N_EVENTS = 64;
+// One pool per device, created on first use under a lock (host threads may drive different devices, or
+// the same device on different streams, at once).  Two concurrent backward passes with side streams on
+// ONE device would share the pool's events; callers that do that must serialise the calls themselves.
 static hipEvent_t* event_pool() {
     static hipEvent_t pool[16][N_EVENTS];
     static bool made[16] = {false};
+    static std::mutex mu;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
     if (!made[dev]) {
         for (int i = 0; i < N_EVENTS; ++i)
             if (hipEventCreateWithFlags(&pool[dev][i], hipEventDisableTiming) != hipSuccess) return nullptr;

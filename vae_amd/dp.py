@@ -2,9 +2,11 @@
 RCCL (torch.distributed backend "nccl" on ROCm), overlapped with the backward pass.
 
 The reference is single-process (no torch.distributed call anywhere); this is the batch
-data-parallel step the MI355X build adds.  Parameters, optimizer state and BatchNorm running
-stats are replicated; BatchNorm batch statistics stay per rank (the single-process semantics
-at the local batch).  The backward pass finishes layers in three stages (decoder + latent
+data-parallel step the MI355X build adds.  Parameters and optimizer state are replicated (same
+start, same averaged gradients).  BatchNorm batch statistics stay per rank (the single-process
+semantics at the local batch), so the running statistics -- broadcast once at start -- drift
+apart from rank to rank afterwards; `sync_bn_stats` averages them (call it before an eval pass
+or a checkpoint if one set of statistics for all ranks is wanted).  The backward pass finishes layers in three stages (decoder + latent
 heads, conv4+conv3, conv2+conv1); each stage's slice of the flat gradient buffer is contiguous,
 so its buckets are plain views (no copy) and are all-reduced on the process group's own stream
 while the next stage computes."""
@@ -80,6 +82,15 @@ class BucketedReducer:
             if not self.avg_op:
                 self.flat[a:b].div_(self.world)
         self.handles = []
+
+
+def sync_bn_stats(model, group=None):
+    """running_mean / running_var of every BatchNorm := mean over ranks (num_batches_tracked is already equal:
+    every rank counts the same steps)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    dist.all_reduce(model._bn_stats, group=group)
+    model._bn_stats.div_(dist.get_world_size(group))
 
 
 def broadcast_state(model, src: int = 0, group=None):

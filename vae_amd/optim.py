@@ -31,6 +31,7 @@ class FlatAdamW:
     def step_flat(self, model=None, max_norm=1.0):
         """clip_grad_norm_(max_norm) + AdamW step on model.flat_grads, then refresh the bf16 weights."""
         m = self.model
+        _lib.check_device(m.flat_params)
         self.step_count += 1
         _lib.call("vae_adamw_clip_step", m.flat_params.data_ptr(), m.flat_grads.data_ptr(), self.exp_avg.data_ptr(),
                   self.exp_avg_sq.data_ptr(), m.flat_params.numel(), self._partial.data_ptr(), float(self.grad_mul),

@@ -17,8 +17,10 @@ import yaml
 
 from . import _lib
 
-RECON_KINDS = {"l1": 0, "mse": 1, "bce": 2, "bce_logits": 3}
-_CALLABLE_KINDS = {F.l1_loss: 0, F.mse_loss: 1, F.binary_cross_entropy: 2, F.binary_cross_entropy_with_logits: 3}
+# "bce_logits" is the draft script's vae_loss_bce (vae/practice/vae_conv.py:146-151): logits clamped to [-10, 10]
+# first, no gradient outside.  The torch callable itself is unclamped ("bce_logits_raw").
+RECON_KINDS = {"l1": 0, "mse": 1, "bce": 2, "bce_logits": 3, "bce_logits_raw": 4}
+_CALLABLE_KINDS = {F.l1_loss: 0, F.mse_loss: 1, F.binary_cross_entropy: 2, F.binary_cross_entropy_with_logits: 4}
 
 
 # ---------------------------------------------------------------------- config (train.py:443-453)
@@ -68,7 +70,7 @@ def _kind_of(loss) -> int:
     if loss in _CALLABLE_KINDS:
         return _CALLABLE_KINDS[loss]
     raise ValueError("reconstruction loss must be one of F.l1_loss, F.mse_loss, F.binary_cross_entropy, "
-                     "F.binary_cross_entropy_with_logits or 'l1' | 'mse' | 'bce' | 'bce_logits'")
+                     "F.binary_cross_entropy_with_logits or 'l1' | 'mse' | 'bce' | 'bce_logits' | 'bce_logits_raw'")
 
 
 class _ElboLoss(torch.autograd.Function):
@@ -112,13 +114,20 @@ class _ElboLoss(torch.autograd.Function):
         return d_recon, None, dmu * g, dlv * g, None, None, None
 
 
+def _require_no_percep(config):
+    """The reference adds percep_weight * LPIPS (train.py:49-50).  That term is not computed here, so a config
+    that asks for it would silently train on a different loss: refuse it on every loss entry point."""
+    pw = config.get("percep_weight", 0.0) if isinstance(config, dict) else getattr(config, "percep_weight", 0.0)
+    if float(pw or 0.0) != 0.0:
+        raise NotImplementedError(f"percep_weight={pw}: the LPIPS perceptual term (pretrained VGG) is outside the "
+                                  "MI355X hot path and is not computed: set percep_weight: 0")
+
+
 def vae_loss(input, target, mu: torch.Tensor, logvar: torch.Tensor, loss: Callable, lpips_fn, config):
-    """reference signature (train.py:44).  `loss` selects the reconstruction term."""
-    pw = float(getattr(config, "percep_weight", 0.0) or 0.0)
-    if pw != 0.0 and lpips_fn is not None:
-        raise NotImplementedError("the LPIPS perceptual term is outside the MI355X hot path: set percep_weight: 0")
-    if not input.is_cuda:
-        raise RuntimeError("vae_loss runs on the GPU only (no CPU fallback)")
+    """reference signature (train.py:44).  `loss` selects the reconstruction term; `lpips_fn` is ignored
+    (percep_weight must be 0)."""
+    _require_no_percep(config)
+    _lib.check_device(input)
     return _ElboLoss.apply(input, target, mu, logvar, _kind_of(loss), float(config.kl_weight))
 
 
@@ -146,6 +155,7 @@ def train_step(model, optimizer, inputs, config, eps=None, keep_masks=None, max_
     backward, clip_grad_norm_(1.0), optimizer.step().  Goes through torch autograd (the model
     and the loss are one autograd node each).  Returns the loss as a 0-dim device tensor (the
     caller decides when to .item() it)."""
+    _require_no_percep(config)
     recons, mu, logvar = model(inputs, eps, keep_masks)
     optimizer.zero_grad()
     kind = recon_kind_from_config(config)
@@ -159,6 +169,7 @@ def train_step(model, optimizer, inputs, config, eps=None, keep_masks=None, max_
 def val_step(model, inputs, config, eps=None):
     """The reference's validation body (train.py:350-353): eval-mode forward + the same loss.
     Like the reference, eps is still sampled in eval mode (vae.py:108-111)."""
+    _require_no_percep(config)
     with torch.no_grad():
         recons, mu, logvar = model(inputs, eps)
         kind = recon_kind_from_config(config)
@@ -171,6 +182,7 @@ class FusedStep:
     rest of the backward), then clip + AdamW.  Numerically identical to train_step()."""
 
     def __init__(self, model, optimizer, config, reducer=None, max_norm=1.0):
+        _require_no_percep(config)
         self.model, self.optimizer, self.config, self.reducer, self.max_norm = model, optimizer, config, reducer, max_norm
         self.kind = recon_kind_from_config(config)
         self.kl_weight = float(config.kl_weight)
@@ -213,6 +225,7 @@ class FusedStep:
                 p.grad = g
             torch.nn.utils.clip_grad_norm_(m.parameters(), max_norm=self.max_norm)
             self.optimizer.step()
+            m.repack_weights()        # the torch optimizer wrote the fp32 parameters: refresh the bf16 operand copies
         return out3[0]
 
 
@@ -230,7 +243,9 @@ def fit(model, optimizer, config, train_feed, val_feed, log=None, checkpoint_pat
     stay on the device and are read once per epoch (the reference's ``loss.item()`` every step stalls the stream;
     the numbers are the same).  ``fused=True`` runs ``FusedStep`` (requires ``FlatAdamW``); otherwise the
     autograd ``train_step``."""
+    import torch.distributed as dist
     from .data import save_checkpoint
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
     step = FusedStep(model, optimizer, config, reducer) if fused else None
     best_val_loss = float("inf")
     history = []
@@ -247,9 +262,18 @@ def fit(model, optimizer, config, train_feed, val_feed, log=None, checkpoint_pat
         with torch.no_grad():
             losses = [val_step(model, x, config).clone() for x in batches(val_feed)]
         val_epoch_loss = float(torch.stack(losses).sum()) / max(len(losses), 1) if losses else float("nan")
+        if multi:
+            # Data-parallel ranks see different validation shards and their BatchNorm running statistics drift
+            # apart (batch statistics are per rank).  The epoch losses become the mean over ranks, so every rank
+            # takes the same "improved" decision, and ONE rank writes the file (with its own running statistics).
+            t = torch.tensor([train_epoch_loss, val_epoch_loss], dtype=torch.float64,
+                             device=next(model.parameters()).device)
+            dist.all_reduce(t)
+            train_epoch_loss, val_epoch_loss = (t / dist.get_world_size()).tolist()
         if getattr(config, "save_model", False) and val_epoch_loss < best_val_loss:
             best_val_loss = val_epoch_loss
-            save_checkpoint(model, checkpoint_path)
+            if not multi or dist.get_rank() == 0:
+                save_checkpoint(model, checkpoint_path)
         rec = {"epoch": epoch, "train/loss": train_epoch_loss, "val/loss": val_epoch_loss}
         history.append(rec)
         if log is not None:

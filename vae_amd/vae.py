@@ -11,8 +11,10 @@ CPU tensor or a missing library raises.
 Storage: once the module sits on a GPU all 52 parameters are views into one flat fp32
 buffer (`flat_params`), gradients are produced into a second flat buffer of the same layout
 (`flat_grads`) and BatchNorm running stats live in a third; parameter identity, shapes and
-names are unchanged.  The kernels read bf16 packed copies of the weights that are refreshed
-whenever the flat parameter buffer's version counter moves (optimizer step, load_state_dict).
+names are unchanged.  The kernels read bf16 packed copies of the weights; they are refreshed
+before a pass whenever any parameter's (or the flat buffer's) autograd version counter has
+moved since the last pack -- torch optimizers, load_state_dict, p.copy_() and p.add_() all
+bump the counter of the Parameter they write, not the flat buffer's.
 """
 from __future__ import annotations
 
@@ -105,7 +107,7 @@ class VAEConv(nn.Module):
         self._bn_stats = None
         self._nbt = None
         self._wpack = None
-        self._packed_version = -1
+        self._packed_version = None
         self._ws_pool = {}
         self._last = None           # state of the most recent forward (for the fused train step)
         # True: backward runs the weight-gradient kernels on a second stream beside the dgrad / BatchNorm chain
@@ -176,7 +178,8 @@ class VAEConv(nn.Module):
         self.flat_params, self.flat_grads, self._bn_stats, self._nbt = flat, grads, stats, nbt
         # zero-filled once: the padding of the packed first-conv operand is never rewritten
         self._wpack = torch.zeros(lib.vae_model_wpack_bytes(ctypes.byref(cfg)), dtype=torch.uint8, device=device)
-        self._packed_version = -1
+        self._packed_version = None
+        self._param_list = params
         self._ws_pool = {}
         self._last = None
 
@@ -195,22 +198,35 @@ class VAEConv(nn.Module):
         base = self.flat_grads if base is None else base
         return [base[off:off + n].view(p.shape) for (off, n), p in zip(self._offsets, self._ordered_params())]
 
+    def _weights_signature(self):
+        """Changes whenever torch code has written a parameter since the last pack.  Every in-place write through
+        a Parameter (optimizer.step(), load_state_dict, p.copy_(), p.add_()) bumps THAT tensor's version counter
+        -- the views were attached with `p.data = view`, so they do not share the flat buffer's counter -- and a
+        write through flat_params bumps the flat buffer's.  A re-assigned `.data` shows up as a moved pointer."""
+        ps = self._param_list
+        return (self.flat_params._version, sum(p._version for p in ps), ps[0].data_ptr(), ps[-1].data_ptr())
+
     def repack_weights(self):
         """refresh the bf16 operand copies from flat_params (call after a raw-pointer update)."""
         cfg = self._cfg(1, True)
+        _lib.check_device(self.flat_params)
         _lib.call("vae_model_pack_weights", ctypes.byref(cfg), self.flat_params.data_ptr(), self._wpack.data_ptr(),
                   _lib.current_stream())
-        self._packed_version = self.flat_params._version
+        self._packed_version = self._weights_signature()
 
     def _ensure_ready(self, x):
         if not x.is_cuda:
             raise RuntimeError("VAEConv runs on an MI355X only: move the module and its input to 'cuda' "
                                "(there is no CPU execution path)")
+        _lib.check_device(x)
         if self.flat_params is None or self.flat_params.device != x.device:
             raise RuntimeError("module parameters are not on the input's device: call model.to(inputs.device)")
         if x.dtype != torch.float32:
             raise RuntimeError(f"inputs must be float32 in [0,1] like the reference's ToTensor() output, got {x.dtype}")
-        if self._packed_version != self.flat_params._version:
+        if self._param_list[0].data_ptr() != self.flat_params.data_ptr():
+            raise RuntimeError("a parameter no longer lives in the module's flat buffer (its .data was re-assigned, e.g. "
+                               "load_state_dict(assign=True)): call model.to(device) again to re-attach the parameters")
+        if self._packed_version != self._weights_signature():
             self.repack_weights()
 
     def _workspace(self, batch):
@@ -323,8 +339,7 @@ class VAEConv(nn.Module):
     def reparameterize(self, mu, logvar):
         """z = mu + exp(0.5*logvar) * eps  (vae/models/vae.py:108-111), eps from the module's
         Philox stream (the draw advances rng_step)."""
-        if not mu.is_cuda:
-            raise RuntimeError("VAEConv.reparameterize runs on the GPU only")
+        _lib.check_device(mu)
         mu, logvar = mu.contiguous().float(), logvar.contiguous().float()
         n = mu.numel()
         z = torch.empty_like(mu)
