@@ -64,6 +64,19 @@ int vae_recon_loss_fwd_bwd(const float* recon, const float* target, float* grad,
 int vae_elbo_combine(const float* recon_partial, int n_recon, const float* kl_partial, int n_kl,
                      float kl_weight, float inv_batch, float* out3, void* stream);
 
+/* Allocation-free variant of vae_recon_loss_fwd_bwd + the fold of its partial sums.  No counterpart in the
+ * reference; it exists for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc): the per-workgroup partial sums live in a fixed 16 KB array inside the
+ * library's code object (one copy per GPU, held until the process ends) instead of a caller buffer.
+ *   out3[0] = out3[1] = sum of the `kind` loss over the n_elems elements (fixed summation order: the value
+ *   vae_elbo_combine gives for the partials of vae_recon_loss_fwd_bwd), out3[2] = 0;  grad as above (may be NULL).
+ * n_elems above vae_recon_loss_static_max_elems() (2^32) is rejected.  It calls no hipMalloc / hipFree; work is
+ * enqueued on `stream` only.  Every call on one GPU shares that GPU's array: calls that overlap on one GPU
+ * (different streams, or host threads) race -- serialise them or use vae_recon_loss_fwd_bwd. */
+long vae_recon_loss_static_max_elems(void);
+int vae_recon_loss_fwd_bwd_static(const float* recon, const float* target, float* grad, float* out3,
+                                  long n_elems, int kind, float grad_scale, void* stream);
+
 /* ---- reparameterisation + KL: VAEConv.reparameterize, vae/models/vae.py:108-111, and the KL
  *      term of vae_loss, vae/training/train.py:47 ------------------------------------------ */
 int vae_reparam_grid(long n_elems);

@@ -23,6 +23,8 @@ SIGNATURES = {
     "vae_prof_stop": (c_int, [P, P, P, P, P, c_int]),
     "vae_recon_loss_grid": (c_int, [c_long]),
     "vae_recon_loss_fwd_bwd": (None, [P, P, P, P, c_long, c_int, c_float, P]),
+    "vae_recon_loss_static_max_elems": (c_long, []),
+    "vae_recon_loss_fwd_bwd_static": (None, [P, P, P, P, c_long, c_int, c_float, P]),
     "vae_elbo_combine": (None, [P, c_int, P, c_int, c_float, c_float, P, P]),
     "vae_reparam_grid": (c_int, [c_long]),
     "vae_reparam_kl_fwd": (None, [P, P, P, P, P, P, P, c_long, c_ulonglong, c_uint, c_uint, P]),

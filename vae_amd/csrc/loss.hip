@@ -162,6 +162,58 @@ extern "C" int vae_recon_loss_fwd_bwd(const float* recon, const float* target, f
     return 0;
 }
 
+// ---------------------------------------------------------------- allocation-free variant
+// The per-workgroup partial sums of vae_recon_loss_fwd_bwd normally live in a buffer the caller allocates.  For callers
+// that cannot allocate (code under graph capture, serving loops, harnesses that forbid hipMalloc) the same two kernels
+// run with the partials in a fixed array that is part of the library's code object.  Each GPU holds its own copy of the
+// array at its own address; the address is looked up once per device (hipGetSymbolAddress) and only that device pointer
+// is ever handed to a kernel -- the array's name in host code is a host-side stand-in, not a device address.
+#define VAE_STATIC_PARTIALS 4096
+static __device__ __align__(256) float scratch[VAE_STATIC_PARTIALS];
+
+#include <mutex>
+static int static_partials(float** out) {
+    static float* ptr_of[64] = {nullptr};
+    static std::mutex mu;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+        vae::set_error("vae_recon_loss_fwd_bwd_static: no current device (hipGetDevice failed or index %d >= 64)", dev);
+        return 3;
+    }
+    std::lock_guard<std::mutex> lock(mu);
+    if (!ptr_of[dev]) {
+        float* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) {
+            vae::set_error("vae_recon_loss_fwd_bwd_static: hipGetSymbolAddress failed on device %d: %s", dev, hipGetErrorString(e));
+            return 3;
+        }
+        ptr_of[dev] = p;
+    }
+    *out = ptr_of[dev];
+    return 0;
+}
+
+extern "C" long vae_recon_loss_static_max_elems(void) { return 1L << 32; }
+
+extern "C" int vae_recon_loss_fwd_bwd_static(const float* recon, const float* target, float* grad, float* out3,
+                                             long n_elems, int kind, float grad_scale, void* stream) {
+    VAE_CHECK(out3, "vae_recon_loss_fwd_bwd_static: null output");
+    VAE_CHECK(n_elems <= vae_recon_loss_static_max_elems(),
+              "vae_recon_loss_fwd_bwd_static: n_elems=%ld exceeds the maximum of %ld elements this entry point accepts "
+              "(use vae_recon_loss_fwd_bwd with a caller-provided partial buffer)", n_elems, vae_recon_loss_static_max_elems());
+    const int grid = vae_recon_loss_grid(n_elems);
+    VAE_CHECK(grid <= VAE_STATIC_PARTIALS, "vae_recon_loss_fwd_bwd_static: %d partial sums do not fit the fixed array of %d",
+              grid, VAE_STATIC_PARTIALS);
+    float* partial = nullptr;
+    const int rc = static_partials(&partial);
+    if (rc) return rc;
+    // slots [0, grid) are overwritten by the first kernel and only those are read by the second: nothing to clear
+    const int e = vae_recon_loss_fwd_bwd(recon, target, grad, partial, n_elems, kind, grad_scale, stream);
+    if (e) return e;
+    return vae_elbo_combine(partial, grid, nullptr, 0, 0.f, 1.f, out3, stream);
+}
+
 extern "C" int vae_elbo_combine(const float* recon_partial, int n_recon, const float* kl_partial,
                                 int n_kl, float kl_weight, float inv_batch, float* out3,
                                 void* stream) {
