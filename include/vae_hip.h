@@ -52,6 +52,15 @@ int vae_prof_start(int max_launches);
 int vae_prof_stop(char* names, int* launches, double* total_ms, double* flops, double* bytes,
                   int max_rows);
 
+/* Measurement aid (no counterpart in the reference): picks between kernel variants that compute the same result, so
+ * that they can be timed against each other inside one process.  Keys: "conv3_wide" = 0 choose per launch (default),
+ * 1 always the 4-wave conv3x3 kernel, 2 the 8-wave kernel wherever its geometry allows.  Not thread-safe: set it
+ * while nothing is being launched. */
+int vae_set_tuning(const char* key, int value);
+/* Diagnostic aid: device buffer (>= 128 bytes per workgroup of the launch under study) that the diagnostic kernel
+ * variants selected with vae_set_tuning write cycle-counter stamps to; NULL (default) = none. */
+int vae_set_debug_buffer(void* dev_ptr);
+
 /* ---- ELBO loss: vae_loss(), vae/training/train.py:44-51 -------------------------------- */
 /* number of workgroups (= length of the `partial` array) the loss kernel uses for n_elems */
 int vae_recon_loss_grid(long n_elems);

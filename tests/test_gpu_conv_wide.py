@@ -1,0 +1,51 @@
+"""The 8-wave (256 pixels x 128 channels per workgroup) form of the 3x3 convolution against the 4-wave form and
+against torch: both kernels run the same MFMA chain per output element, so their bf16 outputs must be equal bit for
+bit -- which kernel a launch picks (it depends on the batch size) must never change a result -- and the per-channel
+statistics must agree to fp32 rounding."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from vae_amd import _lib as L
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def conv(mode, x, w, b, n, H, Ci, Co):
+    L.call("vae_set_tuning", b"conv3_wide", mode)
+    try:
+        rows = L.call("vae_conv3x3_stat_rows", n, H, H, Ci, Co)
+        y = torch.empty(n, H, H, Co, device=DEV, dtype=torch.bfloat16)
+        ss = torch.zeros(rows + 32, Co, device=DEV)
+        sq = torch.zeros(rows + 32, Co, device=DEV)
+        L.call("vae_conv3x3_gemm", x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), ss.data_ptr(), sq.data_ptr(),
+               n, H, H, Ci, Co, L.current_stream())
+        torch.cuda.synchronize()
+        return y, ss[:rows].sum(0), sq[:rows].sum(0)
+    finally:
+        L.call("vae_set_tuning", b"conv3_wide", 0)
+
+
+# (images, H = W, Cin, Cout): several tiles per workgroup with one and two channel chunks; one tile per workgroup with
+# four chunks; two tiles of channels (Cout 256); whole images inside a tile (8x8) and image rows (32x32, 64x64);
+# a launch with fewer tiles than workgroups could hold
+@pytest.mark.parametrize("n,H,Ci,Co", [(512, 16, 64, 128), (384, 16, 128, 128), (512, 8, 256, 256), (96, 32, 128, 128),
+                                       (4, 64, 64, 256), (12, 8, 64, 128)])
+def test_wide_kernel_equals_the_four_wave_kernel_and_torch(n, H, Ci, Co):
+    L.load()
+    g = torch.Generator(device=DEV).manual_seed(H * 1000 + Ci + Co + n)
+    x = torch.randn(n, H, H, Ci, device=DEV, generator=g).to(torch.bfloat16)
+    w = (torch.randn(Co, 9, Ci, device=DEV, generator=g) * 0.05).to(torch.bfloat16)
+    b = torch.randn(Co, device=DEV, generator=g)
+    y4, s4, q4 = conv(1, x, w, b, n, H, Ci, Co)
+    y8, s8, q8 = conv(2, x, w, b, n, H, Ci, Co)
+    assert torch.equal(y4, y8)
+    assert ((s4 - s8).abs().max() / s4.abs().max()).item() <= 1e-5
+    assert ((q4 - q8).abs().max() / q4.abs().max()).item() <= 1e-5
+    # and against torch on the same bf16 operands (fp32 accumulation, one rounding of the output)
+    wt = w.float().view(Co, 3, 3, Ci).permute(0, 3, 1, 2).contiguous()
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), wt, b, padding=1).permute(0, 2, 3, 1)
+    err = ((y8.float() - ref).norm() / ref.norm()).item()
+    assert err <= 3e-3, err                      # bf16 output rounding: 2^-9 relative per element
+    assert ((s8 - ref.sum((0, 1, 2))).abs().max() / ref.sum((0, 1, 2)).abs().max()).item() <= 1e-3

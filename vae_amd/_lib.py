@@ -19,6 +19,8 @@ P = c_void_p
 SIGNATURES = {
     "vae_version": (c_int, []),
     "vae_last_error": (c_char_p, []),
+    "vae_set_tuning": (None, [c_char_p, c_int]),
+    "vae_set_debug_buffer": (None, [P]),
     "vae_prof_start": (None, [c_int]),
     "vae_prof_stop": (c_int, [P, P, P, P, P, c_int]),
     "vae_recon_loss_grid": (c_int, [c_long]),

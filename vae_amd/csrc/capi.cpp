@@ -57,6 +57,25 @@ void prof_end(hipStream_t s) {
 }
 }  // namespace vae
 
+namespace vae {
+extern int g_conv3_wide_mode;
+extern unsigned long long* g_conv3_dbg;
+}
+// Diagnostic aid: a device buffer that diagnostic kernel variants write cycle stamps to (null = none).
+extern "C" int vae_set_debug_buffer(void* dev_ptr) {
+    vae::g_conv3_dbg = (unsigned long long*)dev_ptr;
+    return 0;
+}
+// Measurement aid: selects between kernel variants that compute the same result, for A/B timing in one process.
+extern "C" int vae_set_tuning(const char* key, int value) {
+    if (key && !strcmp(key, "conv3_wide")) {          // 0 auto, 1 always the 4-wave kernel, 2 the 8-wave kernel wherever legal
+        vae::g_conv3_wide_mode = value;
+        return 0;
+    }
+    vae::set_error("vae_set_tuning: unknown key '%s'", key ? key : "(null)");
+    return 1;
+}
+
 extern "C" int vae_version(void) { return VAE_HIP_VERSION; }
 extern "C" const char* vae_last_error(void) { return vae::g_err; }
 

@@ -41,6 +41,7 @@ struct PatchTN {
     int R, G, rwshift;    // rows per group, groups per tile, log2(R*W)
     int PR;               // patch rows
     float inv_per;        // 1 / ((R + 2) * (W + 2))
+    unsigned long long* dbg;   // diagnostic builds only: per-workgroup cycle stamps (16 per workgroup), else null
 };
 
 // pixels per tile: 128, or 256 with the 64-channel tile (the mirror image of 128 pixels x 128 channels: the same
@@ -342,6 +343,329 @@ __global__ __launch_bounds__(256, pt_wgs(W, BN, PT_BM)) void conv3_patch_tn_kern
     }
 }
 
+
+// ============================================================================================================
+// The 8-wave form: 256 pixels x 128 output channels per tile, ONE workgroup of 512 threads per CU.
+//
+// Why a second form.  In the 4-wave kernel above every wave issues ~5 global->LDS copies per K-step (4 weight pieces
+// and its share of the patch) beside 32 MFMAs; a copy costs 100-185 cycles of issue, so a wave needs ~1400 cycles per
+// K-step for 512 cycles of matrix work and two waves per SIMD cannot close that gap.  Here the weight tile of a K-step
+// (16 KB) serves twice the pixels and is copied by eight waves: 2 weight pieces + at most 1 patch piece per wave per
+// K-step.  The two waves that share a SIMD (wave w and w + 4) run the K-step in opposite program order -- waves 0-3
+// issue their copies first and then compute, waves 4-7 compute first and copy afterwards -- so one's copy issue sits
+// under the other's MFMAs with a single barrier per K-step.
+//
+// The K-steps of all the tiles a workgroup walks form ONE stream: step s reads ring slot s % 3 (= tap % 3: nine taps
+// per chunk) and, once its barrier is passed, requests the weight tile of step s + 2 -- which may belong to the next
+// tile -- and one eighth-of-a-row-block piece of the NEXT patch (next 64-channel chunk, or the next tile's first
+// chunk) into the other of two patch buffers.  Every wave issues the same number of copies per tap (a piece that does
+// not exist is a zero-fill into a dummy kilobyte), so the counted waits are compile-time constants: before the
+// barrier of a step, everything but the copies issued during the previous step must have landed.
+// The epilogue stages the bf16 tile through the patch buffer that was just consumed, 128 pixels at a time, while the
+// next tile's first patch and weight tiles are already in flight.
+// Per-channel statistics accumulate in registers over all the tiles of the workgroup and are folded once at its end.
+constexpr int WD_BM = 256, WD_BN = 128, WD_QP = 7;
+
+// LDS accesses of the epilogue go through inline asm: while global->LDS copies are in flight the compiler puts
+// s_waitcnt vmcnt(0) in front of every LDS access it can see (the copies are pending LDS writes to it), which would
+// drain the next tile's prefetch and, worse, wait for the global stores of the first half-tile to complete.
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+__device__ __forceinline__ void lds_store_b64(unsigned addr, unsigned lo, unsigned hi) {
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+    const u32x2 v = {lo, hi};
+    asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+// four 16-byte reads and the wait for them in ONE statement (the compiler does not count asm loads)
+__device__ __forceinline__ void lds_load4_b128(unsigned a0, unsigned a1, unsigned a2, unsigned a3, u32x4& r0, u32x4& r1,
+                                               u32x4& r2, u32x4& r3) {
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+                 : "v"(a0), "v"(a1), "v"(a2), "v"(a3)
+                 : "memory");
+}
+
+// STAMPS: diagnostic instantiation that records the cycle counter at the seams of a workgroup's first tiles
+template <int W, bool STAMPS>
+__global__ __launch_bounds__(512, 2) void conv3_wide_kernel(const PatchTN p) {
+    constexpr int W2 = W + 2;
+    constexpr int QROWS = pt_rows(W, WD_BM);
+    constexpr int Q_BYTES = QROWS * PT_ROWB, B_BYTES = WD_BN * PT_ROWB;
+    constexpr int QPIECES = QROWS / 8;
+    static_assert(QROWS % 8 == 0 && QPIECES <= 8 * WD_QP, "patch pieces per wave");
+    constexpr int RING = 2 * Q_BYTES, RED = RING + 3 * B_BYTES, DUMMY = RED + 2 * 4 * WD_BN * 4, TOTAL = DUMMY + 1024;
+    static_assert(TOTAL <= 163840, "LDS budget");
+    constexpr int OROW = WD_BN * 2 + 16;
+    static_assert(128 * OROW <= Q_BYTES, "output half-tile does not fit a patch buffer");
+    // v_mfma_f32_16x16x32_bf16: 4 x 4 output fragments of 16 x 16 per wave tile, two k-steps of 32 per 64-channel chunk
+    // (the 32x32x16 form was measured 6-14 % slower here and spills)
+    constexpr int F = 16, NF = 4, NE = 4, NKS = 2;
+    typedef f32x4 acc_t;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[TOTAL];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // diagnostic build: wave 0 of every workgroup stamps the cycle counter at the seams of its first tiles
+    int nstamp = 0;
+    auto stamp = [&]() {
+        if (STAMPS && p.dbg && wave == 0 && nstamp < 16) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if (lane == 0) p.dbg[(blockIdx.y * gridDim.x + blockIdx.x) * 16 + nstamp] = t;
+            ++nstamp;
+        }
+    };
+    stamp();                                   // 0: kernel entry
+    const int grp = wave >> 2;                 // 0: copies first, 1: copies last
+    const int wm = wave >> 1, wn = wave & 1;   // wave tile: pixels [64 wm, +64) x channels [64 wn, +64)
+    const int n0 = blockIdx.y * WD_BN;
+    const int K = 9 * p.C;
+    const int nchunk = p.C / 64;
+    const int ntiles = p.M / WD_BM;
+    constexpr unsigned OOB = 0xFFFFFFFFu;
+    const unsigned rowb = (unsigned)p.C * 2;
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)((unsigned)p.M * rowb), 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)((unsigned)p.N * (unsigned)K * 2u), 0x00020000);
+    auto tile_h0 = [&](int m0t) { return p.G == 1 ? ((m0t >> p.wshift) & (p.H - 1)) : 0; };
+
+    // ---- weight pieces: rows [8 (wave + 8 i), +8) of the 128-row tile, i = 0, 1
+    unsigned b_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave + 8 * i) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        b_off[i] = ((unsigned)(n0 + row) * (unsigned)K + chunk * 8) * 2u;
+    }
+    auto stage_b = [&](int slot, int koff) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (lptr_t)(smem + RING + slot * B_BYTES + (wave + 8 * i) * 1024), 16,
+                                                     (int)(b_off[i] + (unsigned)(koff * 2)), 0, 0, 0);
+    };
+    // the weight tiles of steps 0 and 1 go out before anything else is computed: they need no other set-up
+    int tile = blockIdx.x;
+    stage_b(0, 0);
+    stage_b(1, p.C);       // tap 1, chunk 0
+
+    // ---- patch pieces of this wave: piece (wave + 8 i) = patch rows [8 (wave + 8 i), +8), lane -> (row, 16-byte chunk)
+    int q_st[WD_QP];
+#pragma unroll
+    for (int i = 0; i < WD_QP; ++i) {
+        const int prow = (wave + 8 * i) * 8 + (lane >> 3);
+        const int per = (p.R + 2) * W2;
+        const int g = p.G == 1 ? 0 : (int)(((float)prow + 0.5f) * p.inv_per);
+        const int rem = prow - g * per;
+        const int rr = (int)(((float)rem + 0.5f) * (1.0f / W2)), xx = rem - rr * W2;
+        int st = ((lane & 7) ^ ((xx >> 1) & 7)) << 18;
+        if (prow < p.PR && xx >= 1 && xx <= W) st |= ((g * p.R + (rr - 1)) * W + (xx - 1) + 256) | (rr << 10) | (1 << 24);
+        q_st[i] = st;
+    }
+    // piece i of the patch of (tile first pixel m0t, its image row h0t, channel offset c0) into patch buffer `buf`;
+    // valid = 0 (nothing follows) or a piece past the patch: a zero-fill into the dummy kilobyte, so that every
+    // wave issues the same number of copies
+    auto stage_piece = [&](int i, int buf, int m0t, int h0t, int c0, bool valid) {
+        int st = q_st[i];
+        asm volatile("" : "+v"(st));
+        const int m = m0t + (st & 1023) - 256, r = ((st >> 10) & 255) - 1;
+        const bool ok = valid && (st >> 24) && (unsigned)(h0t + r) < (unsigned)p.H && (unsigned)m < (unsigned)p.M;
+        const unsigned off = ok ? (unsigned)m * rowb + (unsigned)(c0 * 2 + ((st >> 14) & 0x70)) : OOB;
+        const int piece = wave + 8 * i;
+        const int dst = piece < QPIECES ? buf * Q_BYTES + piece * 1024 : DUMMY;      // wave-uniform
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lptr_t)(smem + dst), 16, (int)off, 0, 0, 0);
+    };
+    {
+        const int m0t = tile * WD_BM, h0t = tile_h0(m0t);
+#pragma unroll
+        for (int i = 0; i < WD_QP; ++i) stage_piece(i, 0, m0t, h0t, 0, true);
+    }
+
+    // ---- fragment addresses (patch buffer 0; += / -= Q_BYTES when the buffers swap).  Fragment of F rows: lane ->
+    // row (lane % F), 16-byte chunk (lane / F) of k-step 0; k-step 1 flips address bit 6 (its chunks are 4 further)
+    int a_addr[NF][3];
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+        const int ml = wm * 64 + i * F + (lane & (F - 1));
+        const int g = ml >> p.rwshift, kr = ml & ((1 << p.rwshift) - 1);
+        const int r = kr >> p.wshift, x = kr & (W - 1);
+        const int prow = (g * (p.R + 2) + r) * W2 + x + 1;            // the pixel one image row up
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+            a_addr[i][d] = (prow + d - 1) * PT_ROWB + (((lane / F) ^ (((x + d) >> 1) & 7)) << 4);
+    }
+    int b_addr[NF];
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+        const int row = wn * 64 + j * F + (lane & (F - 1));
+        b_addr[j] = RING + row * PT_ROWB + (((lane / F) ^ ((row >> 1) & 7)) << 4);
+    }
+    // accumulator register e of channel fragment j: channel chan(j, e) of the wave's 64 (rows of the MFMA result)
+    auto chan = [&](int j, int e) { return j * 16 + (lane >> 4) * 4 + e; };
+    float bv[NF][NE];
+#pragma unroll
+    for (int j = 0; j < NF; ++j)
+#pragma unroll
+        for (int e = 0; e < NE; ++e) bv[j][e] = p.bias ? p.bias[n0 + wn * 64 + chan(j, e)] : 0.f;
+    float ssum[NF][NE], ssq[NF][NE];
+#pragma unroll
+    for (int j = 0; j < NF; ++j)
+#pragma unroll
+        for (int e = 0; e < NE; ++e) ssum[j][e] = ssq[j][e] = 0.f;
+    const bool want_stats = p.stat_sum != nullptr;
+    float* red = (float*)(smem + RED);
+    // everything issued so far (weight tiles 0 and 1, the first patch, the bias row) is waited for here, once
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp();                                   // 1: set-up done, first operands landed (this wave's)
+
+    int pbuf = 0;
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int m0 = tile * WD_BM;
+        acc_t acc[NF][NF];
+#pragma unroll
+        for (int i = 0; i < NF; ++i)
+#pragma unroll
+            for (int j = 0; j < NF; ++j)
+#pragma unroll
+                for (int e = 0; e < NE; ++e) acc[i][j][e] = 0.f;
+        for (int c = 0; c < nchunk; ++c) {
+            // what the patch pieces issued during this chunk are for
+            const bool last_c = c + 1 == nchunk;
+            const int nt = last_c ? tile + (int)gridDim.x : tile;
+            const bool nvalid = nt < ntiles;
+            const int nm0 = nt * WD_BM, nh0 = tile_h0(nm0), nc0 = last_c ? 0 : (c + 1) * 64;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                // everything but the copies issued during the previous step has landed: the previous step issued 3
+                // copies per wave when its tap was <= 6 (weight pieces + one patch piece), else 2.  (The epilogue's
+                // stores are younger still: the first wait of a tile also waits for most of them.)
+                if (tap == 0 || tap == 8) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                barrier_keep_copies();
+                if (tap == 0 && c == 0) stamp();           // 2, 5, ...: the tile's first operands have landed
+                auto issue = [&]() {
+                    const int t2 = tap + 2;
+                    const int tapn = t2 >= 9 ? t2 - 9 : t2;
+                    int cn = t2 >= 9 ? c + 1 : c;
+                    if (cn == nchunk) cn = 0;                        // the next tile starts over (same weights)
+                    stage_b((tap + 2) % 3, tapn * p.C + cn * 64);
+                    if (tap <= 6) stage_piece(tap, pbuf ^ 1, nm0, nh0, nc0, nvalid);
+                };
+                if (grp == 0) issue();
+                const int dh = tap / 3, dw = tap % 3;
+                const int boff = (tap % 3) * B_BYTES;
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    bf16x8 xa[NF], wb[NF];
+#pragma unroll
+                    for (int i = 0; i < NF; ++i) {
+                        int a = a_addr[i][dw];
+                        if (ks) asm volatile("v_xor_b32 %0, 64, %1" : "=v"(a) : "v"(a_addr[i][dw]));     // stays in the loop
+                        xa[i] = *(const bf16x8*)(smem + a + dh * W2 * PT_ROWB);
+                    }
+#pragma unroll
+                    for (int j = 0; j < NF; ++j) {
+                        int b = b_addr[j];
+                        if (ks) asm volatile("v_xor_b32 %0, 64, %1" : "=v"(b) : "v"(b_addr[j]));
+                        wb[j] = *(const bf16x8*)(smem + b + boff);
+                    }
+#pragma unroll
+                    for (int i = 0; i < NF; ++i)
+#pragma unroll
+                        for (int j = 0; j < NF; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
+                }
+                if (grp == 1) issue();
+            }
+            // the buffers swap: the next chunk (or tile) reads the patch that was just prefetched
+            pbuf ^= 1;
+            const int delta = pbuf ? Q_BYTES : -Q_BYTES;
+#pragma unroll
+            for (int i = 0; i < NF; ++i)
+#pragma unroll
+                for (int d = 0; d < 3; ++d) a_addr[i][d] += delta;
+        }
+
+        stamp();                                   // 3, 6, ...: K loop done
+        // ---- epilogue: statistics in registers, bf16 tile through the consumed patch buffer (pbuf ^ 1 after the swap)
+#pragma unroll
+        for (int i = 0; i < NF; ++i)
+#pragma unroll
+            for (int j = 0; j < NF; ++j)
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    // the bias joins after the sum over k, as in the 4-wave kernel: the two kernels give the same bits,
+                    // so which of them a launch picks never changes a result
+                    const float v = acc[i][j][e] + bv[j][e];
+                    acc[i][j][e] = v;
+                    ssum[j][e] += v;
+                    ssq[j][e] += v * v;
+                }
+        const unsigned stg = (unsigned)(size_t)(lptr_t)smem + (unsigned)((pbuf ^ 1) * Q_BYTES);     // LDS byte address
+        barrier_keep_copies();                       // every wave has read the last tap of that patch
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            if ((wm >> 1) == pass) {
+#pragma unroll
+                for (int i = 0; i < NF; ++i) {
+                    const int ml = (wm & 1) * 64 + i * F + (lane & (F - 1));
+#pragma unroll
+                    for (int j = 0; j < NF; ++j)
+#pragma unroll
+                        for (int e = 0; e < NE; e += 4)      // registers e .. e+3: four consecutive channels
+                            lds_store_b64(stg + ml * OROW + (wn * 64 + chan(j, e)) * 2, pack2bf(acc[i][j][e], acc[i][j][e + 1]),
+                                          pack2bf(acc[i][j][e + 2], acc[i][j][e + 3]));
+                }
+            }
+            barrier_keep_copies();
+            {
+                static_assert(128 * (WD_BN / 8) / 512 == 4, "four 16-byte pieces per thread and half-tile");
+                u32x4 v[4];
+                const unsigned a = stg + (tid >> 4) * OROW + (tid & 15) * 16;
+                lds_load4_b128(a, a + 32 * OROW, a + 64 * OROW, a + 96 * OROW, v[0], v[1], v[2], v[3]);
+                bf16_t* o = p.out + (long)(m0 + pass * 128 + (tid >> 4)) * p.N + n0 + (tid & 15) * 8;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) *(u32x4*)(o + (long)q * 32 * p.N) = v[q];
+            }
+            if (pass == 0) barrier_keep_copies();    // the second half overwrites the staging rows
+        }
+        stamp();                                   // 4, 7, ...: epilogue issued
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // copies requested past the last tile land before LDS is released
+    stamp();                                       // stores and copies complete
+
+    if (want_stats) {
+        // sum over the pixels of a fragment = over the 16 consecutive lanes that share a channel
+#pragma unroll
+        for (int j = 0; j < NF; ++j)
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                ssum[j][e] = pt_row16_sum(ssum[j][e]);
+                ssq[j][e] = pt_row16_sum(ssq[j][e]);
+            }
+        if ((lane & (F - 1)) == 0) {
+#pragma unroll
+            for (int j = 0; j < NF; ++j)
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    const int cc = wn * 64 + chan(j, e);
+                    red[wm * WD_BN + cc] = ssum[j][e];              // one owner per (wave row, channel) slot
+                    red[(4 + wm) * WD_BN + cc] = ssq[j][e];
+                }
+        }
+        barrier_keep_copies();
+        if (tid < WD_BN) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { s += red[w * WD_BN + tid]; q += red[(4 + w) * WD_BN + tid]; }
+            p.stat_sum[(long)blockIdx.x * p.N + n0 + tid] = s;
+            p.stat_sq[(long)blockIdx.x * p.N + n0 + tid] = q;
+        }
+    }
+}
+
+// 0: choose per launch, 1: always the 4-wave kernel, 2: the 8-wave kernel wherever its geometry allows
+int g_conv3_wide_mode = 0;
+unsigned long long* g_conv3_dbg = nullptr;      // diagnostic: where the stamping instantiation writes (vae_set_debug_buffer)
+
 static int pt_ilog2(int v) {
     if (v <= 0 || (v & (v - 1))) return -1;
     int s = 0;
@@ -385,9 +709,24 @@ bool conv3_patch_tn_ok(int n_img, int H, int W, int Cin, int Cout) {
 // ceil(tiles / gx) pixel tiles and leave one row of partial statistics.
 struct PtPlan {
     int bm, bn, gx, gy;
+    bool wide;
 };
 static PtPlan pt_plan(long M, int H, int W, int Cout) {
     PtPlan q;
+    q.wide = false;
+    // the 8-wave kernel: whole 256-pixel x 128-channel tiles only, one workgroup per CU; worth it when its jobs
+    // fill at least three quarters of the chip
+    if (g_conv3_wide_mode != 1 && W >= 8 && Cout % WD_BN == 0 && M % WD_BM == 0 && pt_geom_ok(H, W, WD_BM)) {
+        const long jobs = M / WD_BM * (Cout / WD_BN);
+        if (jobs >= 192 || g_conv3_wide_mode == 2) {
+            q.wide = true;
+            q.bm = WD_BM; q.bn = WD_BN; q.gy = Cout / WD_BN;
+            long gx = 256 / q.gy;
+            if (gx > M / WD_BM) gx = M / WD_BM;
+            q.gx = (int)gx;
+            return q;
+        }
+    }
     const long t128 = (M + 127) / 128;
     q.bm = 128;
     q.bn = Cout % 128 == 0 && t128 * (Cout / 128) >= 256 ? 128 : 64;
@@ -417,6 +756,20 @@ int conv3_patch_tn_launch(const void* x, const void* w_packed, const float* bias
     p.inv_per = 1.0f / (float)((p.R + 2) * (W + 2));
     VAE_CHECK(p.PR <= pt_rows(W, plan.bm) && p.rwshift >= 0, "conv3 patch kernel: internal geometry error (PR=%d)", p.PR);
     dim3 grid(plan.gx, plan.gy);
+    if (plan.wide) {
+        ProfScope prof("conv3_wide_kernel", flops, bytes, s);
+#define WIDE_V(V)                                                                                      \
+        switch (W) {                                                                                   \
+            case 8: hipLaunchKernelGGL((conv3_wide_kernel<8, V>), grid, dim3(512), 0, s, p); break;    \
+            case 16: hipLaunchKernelGGL((conv3_wide_kernel<16, V>), grid, dim3(512), 0, s, p); break;  \
+            case 32: hipLaunchKernelGGL((conv3_wide_kernel<32, V>), grid, dim3(512), 0, s, p); break;  \
+            default: hipLaunchKernelGGL((conv3_wide_kernel<64, V>), grid, dim3(512), 0, s, p); break;  \
+        }
+        if (g_conv3_dbg) { p.dbg = g_conv3_dbg; WIDE_V(true) } else { WIDE_V(false) }
+#undef WIDE_V
+        VAE_LAUNCH_CHECK("conv3_wide_kernel");
+        return 0;
+    }
     static char name[2][48] = {"conv3_patch_tn_kernel<64>", "conv3_patch_tn_kernel<128>"};
     ProfScope prof(name[plan.bn == 128], flops, bytes, s);
     switch (W) {
