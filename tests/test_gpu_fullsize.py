@@ -1,8 +1,9 @@
 """The benchmark configurations at their FULL sizes (batch 512 at 32x32, latent 128; batch 1024 at 64x64, latent 256).
 
 At batch 512 / 32x32 the CPU oracle still finishes a forward pass in seconds, so the train-mode forward, the loss and the gradients are
-compared with it directly (eps and dropout masks from the Philox streams, regenerated on the host).  At 64x64 the
-oracle is too slow; there the checks are properties that do not depend on the size: the pass is bit-reproducible,
+compared with it directly (eps and dropout masks from the Philox streams, regenerated on the host).  At batch 1024 / 64x64 the
+oracle's forward pass ran on the build machine and its digests are a committed fixture (tests/golden/b64_full1024.npz); beyond that
+the checks there are properties that do not depend on the size: the pass is bit-reproducible,
 an eval-mode batch equals the concatenation of its halves to fp32 rounding (no kernel may mix samples outside
 BatchNorm's batch statistics), staged and whole backward agree, and a training step moves the loss down."""
 import pytest
@@ -61,6 +62,35 @@ def test_cfg2_forward_and_loss_against_the_oracle():
     total = dot / (n_got * n_ref) ** 0.5
     print("gradient cosine at batch 512: all parameters", total, "worst tensor", worst)
     assert total >= 0.995
+
+
+def test_cfg4_full_size_forward_and_loss_against_the_oracle_fixture():
+    """Benchmark config 4 at its full size (batch 1024, 64x64, latent 256, dropout 0.1, train mode): the fp32 oracle
+    needs minutes and ~20 GB for it, so it ran on the build machine (oracle/make_fullsize_fixture.py) and left
+    digests -- norm, sum and 16384 strided samples of recon / mu / logvar, the loss, the per-image L1 sums.  Weights,
+    input, eps and the dropout masks are regenerated here from the same seeds (the module's own Philox streams)."""
+    import os
+    import numpy as np
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "b64_full1024.npz"))
+    N, L, S, seed, step, xseed = (int(v) for v in z["cfg"])
+    m = _model(L, S, seed).train()
+    m.rng_step = step
+    x = torch.rand(N, 3, S, S, generator=torch.Generator().manual_seed(xseed))
+    xd = x.to(DEV)
+    recon, mu, logvar = m(xd)
+    from vae_amd.train import Config, l1_kl_percep_loss
+    loss = l1_kl_percep_loss(recon, xd, mu, logvar, Config(kl_weight=1.0, percep_weight=0.0), None)
+    ref_loss = float(z["loss/l1"])
+    assert abs(float(loss.detach()) - ref_loss) <= 1e-2 * abs(ref_loss), (float(loss.detach()), ref_loss)
+    for name, t, tol in (("recon", recon, 2e-2), ("mu", mu, 5e-2), ("logvar", logvar, 5e-2)):
+        dig, smp = O.tensor_digest(t.detach().float().cpu(), 16384)
+        ref_dig, ref_smp = z[f"{name}/digest"], z[f"{name}/sample"]
+        assert abs(dig[0] - ref_dig[0]) <= tol * ref_dig[0], (name, dig[0], ref_dig[0])
+        err = np.linalg.norm(smp.astype(np.float64) - ref_smp) / np.linalg.norm(ref_smp.astype(np.float64))
+        print(f"cfg4 full size: {name} relative L2 error on {ref_smp.size} samples {err:.4f}, norm {dig[0]:.3f} vs {ref_dig[0]:.3f}")
+        assert err <= tol, (name, err)
+    per_image = (recon.detach() - xd).abs().sum(dim=(1, 2, 3)).cpu().numpy()
+    assert np.abs(per_image - z["per_image_l1"]).max() <= 2e-2 * np.abs(z["per_image_l1"]).max()
 
 
 @pytest.mark.parametrize("N,L,S", [(512, 128, 32), (1024, 256, 64)])

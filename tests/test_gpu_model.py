@@ -69,9 +69,19 @@ def test_construction_matches_reference(name):
 #    mu/logvar to the measured bf16 noise level; shallow gradients (head, bn1) to 2e-2; every
 #    gradient tensor must point the same way as both the bf16 oracle's and the fp32 reference's
 #    (cosine) with the same magnitude -- a wiring, layout or scaling bug gives cosine ~0 or a wrong norm.
-EMU_RECON_RTOL = 5e-3
-EMU_DEEP_RTOL = 2.5e-2
+# Measured (profiles/r02_parity.json, tools_parity_report.py) and asserted at about 1.5x the measurement, as RELATIVE L2:
+#   vs the bf16-faithful oracle: recon 1.0-1.2e-3, mu / logvar 0.3-1.0e-2, worst gradient tensor 0.11-0.20, all
+#   gradients together 0.06-0.09 on the 2-4 image fixtures (1.5e-2 at batch 512);
+#   vs the fp32 reference:       recon 1.3-1.5e-3, mu / logvar 2.6-3.7e-2, worst gradient tensor 0.33-0.40.
+# The same bf16 oracle evaluated with a renumbered channel order (identical operands and mathematics, another fp32
+# summation order) differs from ITSELF by recon 1.1e-3, mu / logvar 0.7-1.0e-2, worst gradient tensor 0.13-0.16
+# (tests/test_oracle_bf16_noise_floor.py): that is the floor of any comparison between two bf16 pipelines.
+EMU_RECON_RTOL = 2e-3
+EMU_DEEP_RTOL = 1.6e-2
 DEEP_RTOL = 5e-2
+GRAD_REL_EMU = 0.30          # per gradient tensor, vs the bf16 oracle
+GRAD_REL_EMU_ALL = 0.13      # all gradients as one vector, vs the bf16 oracle
+GRAD_REL_REF = 0.60          # per gradient tensor, vs the fp32 reference
 GRAD_COS_EMU = 0.97
 # against the fp32 reference the bar sits below the worst case of the bf16 oracle itself: on the 4-image fixtures
 # a 64-entry BatchNorm bias gradient of the first block lands at 0.90 +- 0.01 depending on the summation order
@@ -150,6 +160,11 @@ def test_forward_loss_backward_vs_golden(name):
                 report.append((k, rel_l2(g, e_grads[k]), ce, ne, r, cr, nr))
                 assert ce >= GRAD_COS_EMU and abs(ne - 1) <= 0.1, (k, ce, ne)
                 assert cr >= GRAD_COS_REF and abs(nr - 1) <= 0.15, (k, cr, nr)
+                assert rel_l2(g, e_grads[k]) <= GRAD_REL_EMU, (k, rel_l2(g, e_grads[k]))
+                assert rel_l2(g, ref_grads[k]) <= GRAD_REL_REF, (k, rel_l2(g, ref_grads[k]))
+            flat = lambda d: torch.cat([d[k].reshape(-1).double() for k, _, *_ in report])
+            got_all = torch.cat([pp.grad.detach().cpu().reshape(-1).double() for k, pp in m.named_parameters() if not zero_grad_bias(k)])
+            assert rel_l2(got_all, flat(e_grads)) <= GRAD_REL_EMU_ALL, rel_l2(got_all, flat(e_grads))
             wk = max(report, key=lambda t: t[1])
             print(f"{name}/{kind}: worst gradient vs bf16 oracle: {wk[0]} rel {wk[1]:.3f} cos {wk[2]:.4f}; "
                   f"vs fp32 reference rel {wk[4]:.3f} cos {wk[5]:.4f}")
