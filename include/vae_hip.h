@@ -75,11 +75,11 @@ int vae_elbo_combine(const float* recon_partial, int n_recon, const float* kl_pa
 
 /* Allocation-free variant of vae_recon_loss_fwd_bwd + the fold of its partial sums.  No counterpart in the
  * reference; it exists for callers that cannot allocate device memory (code under HIP graph capture, tight serving
- * loops, harnesses that forbid hipMalloc): the per-workgroup partial sums live in a fixed 16 KB array inside the
+ * loops, harnesses that forbid hipMalloc): the per-workgroup partial sums live in a fixed 64 KB array inside the
  * library's code object (one copy per GPU, held until the process ends) instead of a caller buffer.
  *   out3[0] = out3[1] = sum of the `kind` loss over the n_elems elements (fixed summation order: the value
  *   vae_elbo_combine gives for the partials of vae_recon_loss_fwd_bwd), out3[2] = 0;  grad as above (may be NULL).
- * n_elems above vae_recon_loss_static_max_elems() (2^32) is rejected.  It calls no hipMalloc / hipFree; work is
+ * n_elems above vae_recon_loss_static_max_elems() (2^25 = 33 554 432: one partial sum per 2048 elements) is rejected.  It calls no hipMalloc / hipFree; work is
  * enqueued on `stream` only.  Every call on one GPU shares that GPU's array: calls that overlap on one GPU
  * (different streams, or host threads) race -- serialise them or use vae_recon_loss_fwd_bwd. */
 long vae_recon_loss_static_max_elems(void);

@@ -140,3 +140,35 @@ def test_adamw_clip_step_matches_oracle(L, n):
         assert rel_l2(pd.cpu(), params["w"]) <= 1e-6
         assert rel_l2(md.cpu(), m["w"]) <= 1e-5 and rel_l2(vd.cpu(), v["w"]) <= 1e-5
         grads["w"] = grad.clone()      # the oracle clipped in place; the kernel leaves grads untouched
+
+
+@pytest.mark.parametrize("L_,C,hw", [(128, 256, 16), (64, 256, 64), (72, 64, 36), (128, 256, 4)])
+def test_multi_pack_transposing_jobs(L, L_, C, hw):
+    """the nn.Linear weight jobs of the model's pack (vae/models/vae.py:94 flatten order -> NHWC order, and the
+    transposed copies of the input-gradient GEMMs): jobs whose source and destination run along different dims go
+    through LDS tiles when both dims are long enough; sizes here include tile edges that are not full (72, 36) and a
+    source-fastest dim too short for the tiled form (4: the gathering form).  bf16 of the permuted source, exactly."""
+    g = torch.Generator().manual_seed(L_ + C + hw)
+    F_ = C * hw
+    w_mu = torch.randn(L_, F_, generator=g)          # fc_mu.weight [L][(c, p)]
+    w_up = torch.randn(F_, L_, generator=g)          # fc_up.weight [(c, p)][L]
+    dmu, dup = w_mu.to(DEV), w_up.to(DEV)
+    fc_f = torch.zeros(L_, hw, C, device=DEV, dtype=torch.bfloat16)       # [l][p][c]
+    fc_d = torch.zeros(hw, C, 2 * L_, device=DEV, dtype=torch.bfloat16)   # [(p, c)][2L], this job fills columns < L
+    up_d = torch.zeros(L_, hw, C, device=DEV, dtype=torch.bfloat16)       # [l][(p, c)]
+
+    class Job(ctypes.Structure):
+        _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("dims", ctypes.c_long * 4),
+                    ("strides", ctypes.c_long * 4), ("base", ctypes.c_long), ("f32", ctypes.c_int)]
+    l4 = lambda *v: (ctypes.c_long * 4)(*v)
+    jobs = (Job * 3)()
+    jobs[0] = Job(dmu.data_ptr(), fc_f.data_ptr(), l4(L_, C, hw, 1), l4(F_, 1, C, 0), 0, 0)
+    jobs[1] = Job(dmu.data_ptr(), fc_d.data_ptr(), l4(L_, C, hw, 1), l4(1, 2 * L_, C * 2 * L_, 0), 0, 0)
+    jobs[2] = Job(dup.data_ptr(), up_d.data_ptr(), l4(C, hw, L_, 1), l4(1, C, F_, 0), 0, 0)
+    L.call("vae_multi_pack", jobs, 3, L.current_stream())
+    bf = lambda t: t.to(torch.bfloat16).float()
+    w3 = w_mu.view(L_, C, hw)
+    assert torch.equal(fc_f.float().cpu(), bf(w3.permute(0, 2, 1)))
+    assert torch.equal(fc_d.float().cpu()[:, :, :L_], bf(w3.permute(2, 1, 0)))
+    assert float(fc_d.float().abs().cpu()[:, :, L_:].max()) == 0.0
+    assert torch.equal(up_d.float().cpu(), bf(w_up.view(C, hw, L_).permute(2, 1, 0)))

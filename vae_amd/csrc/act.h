@@ -26,6 +26,21 @@ __device__ __forceinline__ void load8(const bf16_t* p, float v[8]) {
 __device__ __forceinline__ void store8(bf16_t* p, const float v[8]) {
     *(uint4*)p = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
 }
+// the same as one-pass streams: non-temporal (the line is not kept for this CU; measured +10 % on read-once /
+// write-once kernels).  Use for tensors this kernel touches once; re-read tensors keep the plain forms.
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4s;
+__device__ __forceinline__ void load8s(const bf16_t* p, float v[8]) {
+    const u32x4s u = __builtin_nontemporal_load((const u32x4s*)p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[2 * i] = __uint_as_float(u[i] << 16);
+        v[2 * i + 1] = __uint_as_float(u[i] & 0xFFFF0000u);
+    }
+}
+__device__ __forceinline__ void store8s(bf16_t* p, const float v[8]) {
+    const u32x4s u = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+    __builtin_nontemporal_store(u, (u32x4s*)p);
+}
 __device__ __forceinline__ void load8f(const float* p, float v[8]) {
     const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
     v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;

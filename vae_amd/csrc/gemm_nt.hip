@@ -331,12 +331,64 @@ struct PackJob {
     long base;
     int f32;             // 1: fp32 permuting copy, 0: bf16 pack
     int vec8;            // innermost destination run is contiguous and a multiple of 8
+    // tiled form (a transposition: the source's fastest dim is not the destination's): 64 x 32 tiles through LDS,
+    // read along the source's fastest dim `si`, written along the destination's fastest dim `di`
+    int tiled, si, di, r0, r1;            // r0, r1: the two other dims
+    int dim[4];                           // sizes in SOURCE order
+    long dst_stride[4];                   // destination strides in source order (dst_stride[di] == 1)
+    int tiles_d, tiles_s;
 };
 struct PackJobs {
     PackJob j[VAE_MAX_PACK_JOBS];
 };
+// A job whose source and destination run along different dims (the nn.Linear weights: NCHW-flatten columns -> NHWC
+// order, and the transposed copies for the input-gradient GEMMs).  Gathering 4-byte elements a row apart costs a
+// memory transaction per element; here a 64 (destination-fastest) x 32 (source-fastest) tile is read in 128-byte
+// runs, turned in LDS and written as 16 bytes (8 bf16) per lane in 128-byte runs.
+__device__ __forceinline__ void pack_tiled(const PackJob& jb, float (*tile)[33]) {
+    const long ntile = (long)jb.dim[jb.r0] * jb.dim[jb.r1] * jb.tiles_d * jb.tiles_s;
+    const long sstride[4] = {(long)jb.dim[1] * jb.dim[2] * jb.dim[3], (long)jb.dim[2] * jb.dim[3], jb.dim[3], 1};
+    for (long t = blockIdx.x; t < ntile; t += gridDim.x) {
+        long q = t;
+        const int ts = (int)(q % jb.tiles_s); q /= jb.tiles_s;
+        const int td = (int)(q % jb.tiles_d); q /= jb.tiles_d;
+        const int i1 = (int)(q % jb.dim[jb.r1]);
+        const int i0 = (int)(q / jb.dim[jb.r1]);
+        const long sbase = i0 * sstride[jb.r0] + i1 * sstride[jb.r1];
+        const long dbase = jb.base + i0 * jb.dst_stride[jb.r0] + i1 * jb.dst_stride[jb.r1];
+        const int d0 = td * 64, s0 = ts * 32;
+        // read: lane -> source-fastest index (32 consecutive floats per row), 8 destination rows per pass
+        {
+            const int sl = threadIdx.x & 31, dl = threadIdx.x >> 5;
+#pragma unroll
+            for (int ps = 0; ps < 8; ++ps) {
+                const int d = d0 + dl + 8 * ps, sx = s0 + sl;
+                float v = 0.f;
+                if (d < jb.dim[jb.di] && sx < jb.dim[jb.si]) v = jb.src[sbase + (long)d * sstride[jb.di] + sx];
+                tile[dl + 8 * ps][sl] = v;
+            }
+        }
+        __syncthreads();
+        // write: lane -> 8 consecutive destination elements of one source-fastest index
+        {
+            const int d8 = (threadIdx.x & 7) * 8, sl = threadIdx.x >> 3;
+            const int sx = s0 + sl;
+            if (sx < jb.dim[jb.si] && d0 + d8 < jb.dim[jb.di]) {       // dim[di] % 8 == 0 (checked on the host)
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = tile[d8 + k][sl];
+                const long d = dbase + (long)sx * jb.dst_stride[jb.si] + d0 + d8;
+                *(uint4*)((bf16_t*)jb.dst + d) = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+            }
+        }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void multi_pack_kernel(const PackJobs jobs) {
+    __shared__ float tile[64][33];
     const PackJob& jb = jobs.j[blockIdx.y];
+    if (jb.tiled) { pack_tiled(jb, tile); return; }
     const int step = jb.vec8 ? 8 : 1;
     const int items = jb.n / step;
     // Workgroups go round-robin over the 8 XCDs, each with its own L2, and neighbouring destination runs gather from
@@ -609,12 +661,26 @@ extern "C" int vae_multi_pack(const vae_pack_job* jobs, int njobs, void* stream)
         bool aligned = jobs[i].base % 8 == 0 && ((uintptr_t)jobs[i].dst & 15) == 0;
         for (int k = 0; k < 3; ++k) aligned = aligned && (dims[ord[k]] == 1 || q.ds[k] % 8 == 0);
         q.vec8 = !jobs[i].f32 && q.ds[3] == 1 && q.d3 % 8 == 0 && aligned;
-        const int items = (int)(n / (q.vec8 ? 8 : 1));
+        // a transposition of two large dims goes through LDS tiles: source-fastest dim si (the last dim of size > 1),
+        // destination-fastest dim di (stride 1)
+        q.tiled = 0;
+        int si = 3;
+        while (si > 0 && dims[si] == 1) --si;
+        const int di = ord[3];
+        if (q.vec8 && si != di && dims[si] >= 16 && dims[di] >= 64 && dims[di] % 8 == 0) {
+            q.tiled = 1; q.si = si; q.di = di;
+            int rest[2], nr = 0;
+            for (int k = 0; k < 4; ++k) if (k != si && k != di) rest[nr++] = k;
+            q.r0 = rest[0]; q.r1 = rest[1];
+            for (int k = 0; k < 4; ++k) { q.dim[k] = (int)dims[k]; q.dst_stride[k] = jobs[i].strides[k]; }
+            q.tiles_d = (int)((dims[di] + 63) / 64); q.tiles_s = (int)((dims[si] + 31) / 32);
+        }
+        const int items = q.tiled ? (int)(n / 8) : (int)(n / (q.vec8 ? 8 : 1));      // a tile holds 2048 elements = 256 items
         if (items > max_items) max_items = items;
         bytes += n * (jobs[i].f32 ? 8.0 : 6.0);
     }
     int gx = (max_items + 255) / 256;
-    if (gx > 128) gx = 128;
+    if (gx > 1024) gx = 1024;
     if (gx > 8) gx &= ~7;          // whole rounds of the 8 XCDs (the kernel then keeps each XCD on its own part of a job)
     ProfScope prof("multi_pack_kernel", 0.0, bytes, (hipStream_t)stream);
     hipLaunchKernelGGL(multi_pack_kernel, dim3(gx, njobs), dim3(256), 0, (hipStream_t)stream, pj);

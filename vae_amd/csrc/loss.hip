@@ -43,7 +43,24 @@ __device__ __forceinline__ void loss_elem(float r, float t, float gs, float& l, 
     }
 }
 
-template <int KIND, bool WRITE_GRAD>
+// Streaming shape (measured on 3 x 256 MiB): one workgroup per contiguous run of LOSS_CHUNK elements, two float4 per
+// lane and array, non-temporal loads and stores, as many workgroups as there are runs -- 6.3 TB/s.  The same arithmetic
+// as a grid-stride loop over a grid capped at 2048 workgroups with plain loads ran at 5.0-5.3 TB/s.
+constexpr int LOSS_CHUNK = 2048;        // elements per workgroup = 256 lanes x 2 x float4
+
+typedef __attribute__((ext_vector_type(4))) float f32x4v;
+__device__ __forceinline__ float4 ld_stream(const float4* p) {
+    const f32x4v v = __builtin_nontemporal_load((const f32x4v*)p);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void st_stream(float4* p, const float4& g) {
+    const f32x4v v = {g.x, g.y, g.z, g.w};
+    __builtin_nontemporal_store(v, (f32x4v*)p);
+}
+
+// GRAD: 0 no gradient, 1 plain stores (the gradient is read back at once by the next kernel: leave it in L2), 2 non-temporal
+// stores (a gradient larger than the caches)
+template <int KIND, int GRAD>
 __global__ __launch_bounds__(256) void recon_loss_kernel(const float* __restrict__ recon,
                                                          const float* __restrict__ target,
                                                          float* __restrict__ grad,
@@ -55,14 +72,12 @@ __global__ __launch_bounds__(256) void recon_loss_kernel(const float* __restrict
     const float4* r4 = (const float4*)recon;
     const float4* t4 = (const float4*)target;
     float4* g4 = (float4*)grad;
-    // two float4 pairs per trip: four 16-byte loads in flight per lane (a streaming kernel lives on bytes in flight)
-    const long stride = (long)gridDim.x * blockDim.x;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += 2 * stride) {
-        const long j = i + stride;
-        const bool two = j < n4;
-        const float4 r = r4[i], t = t4[i];
-        float4 r2 = r, t2 = t;
-        if (two) { r2 = r4[j]; t2 = t4[j]; }
+    const long i = (long)blockIdx.x * (LOSS_CHUNK / 4) + threadIdx.x, j = i + 256;
+    const bool one = i < n4, two = j < n4;
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f), t = r, r2 = r, t2 = r;
+    if (one) { r = ld_stream(r4 + i); t = ld_stream(t4 + i); }
+    if (two) { r2 = ld_stream(r4 + j); t2 = ld_stream(t4 + j); }
+    if (one) {
         float4 g;
         float l0, l1, l2, l3;
         loss_elem<KIND>(r.x, t.x, gs, l0, g.x);
@@ -70,23 +85,25 @@ __global__ __launch_bounds__(256) void recon_loss_kernel(const float* __restrict
         loss_elem<KIND>(r.z, t.z, gs, l2, g.z);
         loss_elem<KIND>(r.w, t.w, gs, l3, g.w);
         acc += (l0 + l1) + (l2 + l3);
-        if (WRITE_GRAD) g4[i] = g;
-        if (two) {
-            loss_elem<KIND>(r2.x, t2.x, gs, l0, g.x);
-            loss_elem<KIND>(r2.y, t2.y, gs, l1, g.y);
-            loss_elem<KIND>(r2.z, t2.z, gs, l2, g.z);
-            loss_elem<KIND>(r2.w, t2.w, gs, l3, g.w);
-            acc += (l0 + l1) + (l2 + l3);
-            if (WRITE_GRAD) g4[j] = g;
-        }
+        if (GRAD == 2) st_stream(g4 + i, g); else if (GRAD == 1) g4[i] = g;
+    }
+    if (two) {
+        float4 g;
+        float l0, l1, l2, l3;
+        loss_elem<KIND>(r2.x, t2.x, gs, l0, g.x);
+        loss_elem<KIND>(r2.y, t2.y, gs, l1, g.y);
+        loss_elem<KIND>(r2.z, t2.z, gs, l2, g.z);
+        loss_elem<KIND>(r2.w, t2.w, gs, l3, g.w);
+        acc += (l0 + l1) + (l2 + l3);
+        if (GRAD == 2) st_stream(g4 + j, g); else if (GRAD == 1) g4[j] = g;
     }
     // tail (n not a multiple of 4)
     if (blockIdx.x == 0) {
-        for (long i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) {
+        for (long k = (n4 << 2) + threadIdx.x; k < n; k += blockDim.x) {
             float l, g;
-            loss_elem<KIND>(recon[i], target[i], gs, l, g);
+            loss_elem<KIND>(recon[k], target[k], gs, l, g);
             acc += l;
-            if (WRITE_GRAD) grad[i] = g;
+            if (GRAD) grad[k] = g;
         }
     }
     const float s = block_sum(acc, red);
@@ -125,10 +142,9 @@ __global__ __launch_bounds__(256) void elbo_combine_kernel(const float* __restri
 using namespace vae;
 
 extern "C" int vae_recon_loss_grid(long n_elems) {
-    long blocks = (n_elems / 4 + 255) / 256;
+    long blocks = (n_elems + vae::LOSS_CHUNK - 1) / vae::LOSS_CHUNK;       // one workgroup (and one partial sum) per run
     if (blocks < 1) blocks = 1;
-    if (blocks > 2048) blocks = 2048;   // 256 CUs x 8 workgroups, grid-stride beyond
-    return (int)blocks;
+    return blocks > 0x7FFFFFFFL ? -1 : (int)blocks;
 }
 
 extern "C" int vae_recon_loss_fwd_bwd(const float* recon, const float* target, float* grad,
@@ -137,18 +153,23 @@ extern "C" int vae_recon_loss_fwd_bwd(const float* recon, const float* target, f
     VAE_CHECK(recon && target && partial, "vae_recon_loss_fwd_bwd: null pointer");
     VAE_CHECK(n_elems > 0, "vae_recon_loss_fwd_bwd: n_elems must be > 0 (got %ld)", n_elems);
     VAE_CHECK(kind >= 0 && kind <= 4, "vae_recon_loss_fwd_bwd: unknown kind %d", kind);
+    VAE_CHECK(vae_recon_loss_grid(n_elems) > 0, "vae_recon_loss_fwd_bwd: n_elems=%ld too large", n_elems);
     VAE_CHECK(((uintptr_t)recon & 15) == 0 && ((uintptr_t)target & 15) == 0 &&
                   ((uintptr_t)grad & 15) == 0,
               "vae_recon_loss_fwd_bwd: pointers must be 16-byte aligned");
     const int grid = vae_recon_loss_grid(n_elems);
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(grad ? "recon_loss_kernel<fwd+bwd>" : "recon_loss_kernel<fwd>", 0.0, (grad ? 12.0 : 8.0) * n_elems, s);
+    const bool big = n_elems >= (16L << 20);      // 64 MB of gradient and up: it will not be found in a cache anyway
 #define LAUNCH(K)                                                                              \
-    if (grad)                                                                                  \
-        hipLaunchKernelGGL((recon_loss_kernel<K, true>), dim3(grid), dim3(256), 0, s, recon,   \
+    if (grad && big)                                                                           \
+        hipLaunchKernelGGL((recon_loss_kernel<K, 2>), dim3(grid), dim3(256), 0, s, recon,      \
+                           target, grad, partial, n_elems, grad_scale);                        \
+    else if (grad)                                                                             \
+        hipLaunchKernelGGL((recon_loss_kernel<K, 1>), dim3(grid), dim3(256), 0, s, recon,      \
                            target, grad, partial, n_elems, grad_scale);                        \
     else                                                                                       \
-        hipLaunchKernelGGL((recon_loss_kernel<K, false>), dim3(grid), dim3(256), 0, s, recon,  \
+        hipLaunchKernelGGL((recon_loss_kernel<K, 0>), dim3(grid), dim3(256), 0, s, recon,      \
                            target, grad, partial, n_elems, grad_scale);
     switch (kind) {
         case VAE_RECON_L1: LAUNCH(VAE_RECON_L1); break;
@@ -168,7 +189,7 @@ extern "C" int vae_recon_loss_fwd_bwd(const float* recon, const float* target, f
 // run with the partials in a fixed array that is part of the library's code object.  Each GPU holds its own copy of the
 // array at its own address; the address is looked up once per device (hipGetSymbolAddress) and only that device pointer
 // is ever handed to a kernel -- the array's name in host code is a host-side stand-in, not a device address.
-#define VAE_STATIC_PARTIALS 4096
+#define VAE_STATIC_PARTIALS 16384
 static __device__ __align__(256) float scratch[VAE_STATIC_PARTIALS];
 
 #include <mutex>
@@ -194,7 +215,7 @@ static int static_partials(float** out) {
     return 0;
 }
 
-extern "C" long vae_recon_loss_static_max_elems(void) { return 1L << 32; }
+extern "C" long vae_recon_loss_static_max_elems(void) { return (long)VAE_STATIC_PARTIALS * vae::LOSS_CHUNK; }
 
 extern "C" int vae_recon_loss_fwd_bwd_static(const float* recon, const float* target, float* grad, float* out3,
                                              long n_elems, int kind, float grad_scale, void* stream) {

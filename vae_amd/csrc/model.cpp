@@ -174,7 +174,7 @@ void make_ws_layout(const Dims& d, WsLayout* w) {
     const long statn = (stat > stat2 ? stat : stat2) + VAE_STAT_SCRATCH_ROWS * 256L;   // + the fold's scratch rows
     w->stat_sum = put(statn * 4); w->stat_sq = put(statn * 4);
     w->zb = put((long)d.N * d.L * 2);
-    w->klp = put(2048 * 4);
+    w->klp = put((long)vae_reparam_grid((long)d.N * d.L) * 4);
     w->h = put((long)d.N * d.F * 2);
     const int s8 = d.S / 8;
     for (int u = 0; u < 3; ++u) {

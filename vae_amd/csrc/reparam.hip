@@ -156,9 +156,9 @@ __global__ __launch_bounds__(256) void philox_fill_kernel(void* __restrict__ out
 using namespace vae;
 
 extern "C" int vae_reparam_grid(long n_elems) {
-    long blocks = ((n_elems + 3) / 4 + 255) / 256;
+    long blocks = ((n_elems + 3) / 4 + 255) / 256;      // one Philox block (four elements) per lane
     if (blocks < 1) blocks = 1;
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > (1L << 20)) blocks = 1L << 20;         // grid-stride beyond 2^30 elements
     return (int)blocks;
 }
 
