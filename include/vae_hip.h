@@ -54,7 +54,8 @@ int vae_prof_stop(char* names, int* launches, double* total_ms, double* flops, d
 
 /* Measurement aid (no counterpart in the reference): picks between kernel variants that compute the same result, so
  * that they can be timed against each other inside one process.  Keys: "conv3_wide" = 0 choose per launch (default),
- * 1 always the 4-wave conv3x3 kernel, 2 the 8-wave kernel wherever its geometry allows.  Not thread-safe: set it
+ * 1 always the 4-wave conv3x3 kernel, 2 the 8-wave kernel wherever its geometry allows; "conv3_ksplit" = 0 default,
+ * 1 never split K between two wave groups of a workgroup, 2 wherever the chunk count is even.  Not thread-safe: set it
  * while nothing is being launched. */
 int vae_set_tuning(const char* key, int value);
 /* Diagnostic aid: device buffer (>= 128 bytes per workgroup of the launch under study) that the diagnostic kernel

@@ -49,3 +49,25 @@ def test_wide_kernel_equals_the_four_wave_kernel_and_torch(n, H, Ci, Co):
     err = ((y8.float() - ref).norm() / ref.norm()).item()
     assert err <= 3e-3, err                      # bf16 output rounding: 2^-9 relative per element
     assert ((s8 - ref.sum((0, 1, 2))).abs().max() / ref.sum((0, 1, 2)).abs().max()).item() <= 1e-3
+
+
+@pytest.mark.parametrize("n,H,Ci,Co", [(512, 4, 256, 256), (40, 8, 256, 128), (3, 4, 128, 64), (2, 32, 128, 128)])
+def test_split_k_inside_the_workgroup_equals_the_plain_form(n, H, Ci, Co):
+    """two wave groups of one workgroup each sum half of the channel chunks (the form picked for launches with at most
+    one tile per CU): the same sums in two parts, so equal to the plain form to fp32 rounding of the accumulator"""
+    L.load()
+    g = torch.Generator(device=DEV).manual_seed(n + H + Ci + Co)
+    x = torch.randn(n, H, H, Ci, device=DEV, generator=g).to(torch.bfloat16)
+    w = (torch.randn(Co, 9, Ci, device=DEV, generator=g) * 0.05).to(torch.bfloat16)
+    b = torch.randn(Co, device=DEV, generator=g)
+    out = {}
+    for ks in (1, 2):
+        L.call("vae_set_tuning", b"conv3_ksplit", ks)
+        try:
+            out[ks] = conv(1, x, w, b, n, H, Ci, Co)
+        finally:
+            L.call("vae_set_tuning", b"conv3_ksplit", 0)
+    (y1, s1, q1), (y2, s2, q2) = out[1], out[2]
+    assert ((y1.float() - y2.float()).norm() / y1.float().norm()).item() <= 2e-4      # a bf16 rounding flips on ~1e-4 of the elements
+    assert ((s1 - s2).abs().max() / s1.abs().max()).item() <= 1e-5
+    assert ((q1 - q2).abs().max() / q1.abs().max()).item() <= 1e-5

@@ -75,9 +75,16 @@ __device__ __forceinline__ float pt_row16_sum(float v) {
 // workgroups that share a CU: three of the 64-channel form (a third of the LDS and at most 168 VGPRs each), else two
 constexpr int pt_wgs(int W, int BN, int BM = 128) { return BN == 64 && BM == 128 && W != 4 ? 3 : 2; }
 
-template <int W, int BN, int PT_BM>
-__global__ __launch_bounds__(256, pt_wgs(W, BN, PT_BM)) void conv3_patch_tn_kernel(const PatchTN p) {
+// KS = 2 ("split K inside the workgroup"): 512 threads = two groups of four waves that own the SAME output tile; group g
+// runs the loop below over the channel chunks c = g, g + 2, ... with its own patch buffer and weight ring, group 1 hands
+// its accumulators to group 0 through LDS and group 0 runs the epilogue.  For launches with so few tiles that a CU gets
+// one four-wave workgroup (one wave per SIMD: every LDS read -> MFMA latency chain is exposed) this puts two waves
+// on each SIMD and halves the chain (the 4x4 layers: 36 K-steps -> 18).  The sum over k is then split in two partial
+// sums, so results differ from the KS = 1 form in the last bit.
+template <int W, int BN, int PT_BM, int KS = 1>
+__global__ __launch_bounds__(256 * KS, KS == 2 ? 2 : pt_wgs(W, BN, PT_BM)) void conv3_patch_tn_kernel(const PatchTN p) {
     static_assert(PT_BM == 128 || (PT_BM == 256 && BN == 64 && W >= 8), "tile heights: 128, or 256 with the 64-channel tile");
+    static_assert(KS == 1 || PT_BM == 128, "the split form uses 128-pixel tiles");
     constexpr int W2 = W + 2;
     constexpr int WAVES_M = BN == 128 ? 2 : 4, WAVES_N = 4 / WAVES_M;
     constexpr int TM = PT_BM / WAVES_M, TN = BN / WAVES_N;      // wave tile: TM pixels x TN channels
@@ -86,7 +93,7 @@ __global__ __launch_bounds__(256, pt_wgs(W, BN, PT_BM)) void conv3_patch_tn_kern
     constexpr int B_INSTR = BN / 8 / 4;
     constexpr int Q_INSTR = (pt_rows(W, PT_BM) / 8 + 3) / 4;    // patch copies per wave
     // weight tiles sit in a ring as deep as the workgroup's share of the CU's 160 KB allows, at most 4
-    constexpr int LDS_SHARE = (163840 / pt_wgs(W, BN, PT_BM)) / 1280 * 1280;     // whole allocation granules
+    constexpr int LDS_SHARE = (163840 / (KS == 2 ? 2 : pt_wgs(W, BN, PT_BM))) / 1280 * 1280;     // whole allocation granules
     constexpr int AUX_BYTES = 2048 + BN * 4;                       // statistics accumulators + the bias row
     constexpr int DEPTH = (LDS_SHARE - AUX_BYTES - Q_BYTES) / B_BYTES >= 4 ? 4 : (LDS_SHARE - AUX_BYTES - Q_BYTES) / B_BYTES;
     static_assert(TN == 64, "wave tile is 64 channels wide");
@@ -94,10 +101,15 @@ __global__ __launch_bounds__(256, pt_wgs(W, BN, PT_BM)) void conv3_patch_tn_kern
 
     constexpr int RED_BYTES = 2 * WAVES_M * BN * 4;                // statistics accumulators
     static_assert(RED_BYTES + BN * 4 == AUX_BYTES, "auxiliary LDS size");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[Q_BYTES + DEPTH * B_BYTES + AUX_BYTES];
+    constexpr int GROUP_BYTES = Q_BYTES + DEPTH * B_BYTES;        // one group's patch + weight ring
+    static_assert(KS == 1 || 256 * 16 * 16 <= KS * GROUP_BYTES, "the accumulator hand-over does not fit");
+    __shared__ __attribute__((aligned(16))) unsigned char smem_all[KS * GROUP_BYTES + AUX_BYTES];
 
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int lane = threadIdx.x & 63;
+    const int grp = KS == 2 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0;
+    const int tid = threadIdx.x & 255;                            // index inside the group
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: addresses and branches built on it stay scalar
+    unsigned char* const smem = smem_all + grp * GROUP_BYTES;     // this group's staging buffers
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int n0 = blockIdx.y * BN;
     int m0 = 0, h0 = 0;          // first pixel of the current tile and its image row (set per tile below)
@@ -182,20 +194,22 @@ __global__ __launch_bounds__(256, pt_wgs(W, BN, PT_BM)) void conv3_patch_tn_kern
     }
 
     // ---- persistent loop over pixel tiles: the address tables above are computed once per workgroup ----
-    const int nchunk = p.C / 64;
+    const int nchunk_all = p.C / 64;
+    const int nchunk = KS == 2 ? nchunk_all / 2 : nchunk_all;     // this group's chunks (the launcher checks that they split evenly)
     const int ntiles = (p.M + PT_BM - 1) / PT_BM;
-    const int nsteps = 9 * nchunk;                 // K-steps per tile: one (channel chunk, tap) each
+    const int nsteps = 9 * nchunk;                 // K-steps per tile and group: one (channel chunk, tap) each
     int slot = 0;                                  // ring slot of the current K-step's weight tile
     // per-channel statistics of the stored values accumulate over all the tiles of this workgroup in a small LDS
     // array [sum | sum of squares][wave row][channel] (each slot has one owning lane: no atomics, no barrier) and
     // leave as ONE partial row per workgroup
     const bool want_stats = p.stat_sum != nullptr;
-    float* red = (float*)(smem + Q_BYTES + DEPTH * B_BYTES);
-    for (int i = tid; i < 2 * WAVES_M * BN; i += 256) red[i] = 0.f;     // first read is many barriers away
+    float* red = (float*)(smem_all + KS * GROUP_BYTES);
+    if (grp == 0)
+        for (int i = tid; i < 2 * WAVES_M * BN; i += 256) red[i] = 0.f;     // first read is many barriers away
     // the bias row sits in LDS for the life of the workgroup: a global load at the top of every epilogue would expose
     // a memory round trip per tile
     float* bias_lds = red + 2 * WAVES_M * BN;
-    if (tid < BN) bias_lds[tid] = (p.bias && n0 + tid < p.N) ? p.bias[n0 + tid] : 0.f;
+    if (grp == 0 && tid < BN) bias_lds[tid] = (p.bias && n0 + tid < p.N) ? p.bias[n0 + tid] : 0.f;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     if (tile != (int)blockIdx.x) barrier_keep_copies();  // the previous tile's patch and weight tiles are done with
     m0 = tile * PT_BM;
@@ -206,12 +220,13 @@ __global__ __launch_bounds__(256, pt_wgs(W, BN, PT_BM)) void conv3_patch_tn_kern
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    stage_patch(0);
+    const int cbase = grp * 64;                    // this group's first channel chunk; its chunks are KS * 64 apart
+    stage_patch(cbase);
 #pragma unroll
     for (int q = 0; q < DEPTH - 1; ++q)            // K-steps 0 .. DEPTH-2 (nsteps >= 9 > DEPTH)
-        stage_b((slot + q) % DEPTH, q * p.C);
+        stage_b((slot + q) % DEPTH, q * p.C + cbase);
     for (int c = 0; c < nchunk; ++c) {
-        const int c0 = c * 64;
+        const int c0 = cbase + c * KS * 64;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             // K-step s = 9c + tap needs its weight tile (and, on the first tap of a chunk, the patch, which was
@@ -223,7 +238,7 @@ __global__ __launch_bounds__(256, pt_wgs(W, BN, PT_BM)) void conv3_patch_tn_kern
             {   // refill the slot read in the previous K-step with the tile of K-step s + DEPTH - 1
                 const int t2 = tap + DEPTH - 1;
                 const int tapn = t2 >= 9 ? t2 - 9 : t2, cn = t2 >= 9 ? c + 1 : c;
-                if (cn < nchunk) stage_b((slot + DEPTH - 1) % DEPTH, tapn * p.C + cn * 64);
+                if (cn < nchunk) stage_b((slot + DEPTH - 1) % DEPTH, tapn * p.C + cbase + cn * KS * 64);
             }
             const int dh = tap / 3, dw = tap % 3;
             const int boff = slot * B_BYTES;
@@ -252,7 +267,7 @@ __global__ __launch_bounds__(256, pt_wgs(W, BN, PT_BM)) void conv3_patch_tn_kern
         }
         if (c + 1 < nchunk) {
             barrier_keep_copies();            // every wave has read the last tap of this chunk's patch
-            stage_patch(c0 + 64);
+            stage_patch(c0 + KS * 64);
         }
     }
 
@@ -276,6 +291,28 @@ __global__ __launch_bounds__(256, pt_wgs(W, BN, PT_BM)) void conv3_patch_tn_kern
     constexpr int OROW = BN * 2 + 16;
     static_assert(PT_BM * OROW <= Q_BYTES + DEPTH * B_BYTES, "output tile does not fit the staging buffers");
     barrier_keep_copies();                     // every wave is done reading the patch and the weight ring
+    if (KS == 2) {
+        // group 1 -> group 0: one float4 per (fragment, lane), laid out so that a wave's store is 1 KB contiguous
+        float4* hand = (float4*)smem_all + tid;
+        if (grp == 1) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    hand[(i * FN + j) * 256] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        }
+        barrier_keep_copies();
+        if (grp == 0) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    const float4 o = hand[(i * FN + j) * 256];
+                    acc[i][j][0] += o.x; acc[i][j][1] += o.y; acc[i][j][2] += o.z; acc[i][j][3] += o.w;
+                }
+        }
+        barrier_keep_copies();                 // the hand-over area is the output staging area below
+    }
     const bool full = m0 + PT_BM <= p.M && n0 + BN <= p.N;
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
@@ -294,7 +331,7 @@ __global__ __launch_bounds__(256, pt_wgs(W, BN, PT_BM)) void conv3_patch_tn_kern
                     ssq[j][r] += v[r] * v[r];
                 }
             }
-            *(uint2*)(smem + ml * OROW + nl * 2) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+            if (grp == 0) *(uint2*)(smem + ml * OROW + nl * 2) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
         }
     }
     barrier_keep_copies();
@@ -305,10 +342,10 @@ __global__ __launch_bounds__(256, pt_wgs(W, BN, PT_BM)) void conv3_patch_tn_kern
             const int cidx = q * 256 + tid;
             const int row = cidx / CPR, ch = cidx % CPR;
             const int m = m0 + row, n = n0 + ch * 8;
-            if (m < p.M && n < p.N) *(uint4*)(p.out + (long)m * p.N + n) = *(const uint4*)(smem + row * OROW + ch * 16);
+            if (grp == 0 && m < p.M && n < p.N) *(uint4*)(p.out + (long)m * p.N + n) = *(const uint4*)(smem + row * OROW + ch * 16);
         }
     }
-    if (want_stats) {
+    if (want_stats && grp == 0) {
         // all 16-lane sums first (32 independent DPP chains the scheduler can interleave), then one predicated block
 #pragma unroll
         for (int j = 0; j < FN; ++j)
@@ -333,7 +370,7 @@ __global__ __launch_bounds__(256, pt_wgs(W, BN, PT_BM)) void conv3_patch_tn_kern
 
     if (want_stats) {
         barrier_keep_copies();
-        if (tid < BN && n0 + tid < p.N) {
+        if (grp == 0 && tid < BN && n0 + tid < p.N) {
             float s = 0.f, q = 0.f;
 #pragma unroll
             for (int w = 0; w < WAVES_M; ++w) { s += red[w * BN + tid]; q += red[(WAVES_M + w) * BN + tid]; }
@@ -664,6 +701,8 @@ __global__ __launch_bounds__(512, 2) void conv3_wide_kernel(const PatchTN p) {
 
 // 0: choose per launch, 1: always the 4-wave kernel, 2: the 8-wave kernel wherever its geometry allows
 int g_conv3_wide_mode = 0;
+// 0: choose per launch, 1: never split K inside the workgroup, 2: wherever the chunk count is even
+int g_conv3_ksplit_mode = 0;
 unsigned long long* g_conv3_dbg = nullptr;      // diagnostic: where the stamping instantiation writes (vae_set_debug_buffer)
 
 static int pt_ilog2(int v) {
@@ -674,7 +713,12 @@ static int pt_ilog2(int v) {
 }
 
 template <int W>
-static void pt_launch_w(const PatchTN& p, dim3 grid, int bn, int bm, hipStream_t s) {
+static void pt_launch_w(const PatchTN& p, dim3 grid, int bn, int bm, int ks, hipStream_t s) {
+    if (ks == 2) {
+        if (bn == 64) hipLaunchKernelGGL((conv3_patch_tn_kernel<W, 64, 128, 2>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((conv3_patch_tn_kernel<W, 128, 128, 2>), grid, dim3(512), 0, s, p);
+        return;
+    }
     if constexpr (W >= 8) {
         if (bm == 256) { hipLaunchKernelGGL((conv3_patch_tn_kernel<W, 64, 256>), grid, dim3(256), 0, s, p); return; }
     }
@@ -708,12 +752,13 @@ bool conv3_patch_tn_ok(int n_img, int H, int W, int Cin, int Cout) {
 // channels, 256-pixel tiles when those still give every CU two workgroups.  gx workgroups along M each walk
 // ceil(tiles / gx) pixel tiles and leave one row of partial statistics.
 struct PtPlan {
-    int bm, bn, gx, gy;
+    int bm, bn, gx, gy, ks;
     bool wide;
 };
-static PtPlan pt_plan(long M, int H, int W, int Cout) {
+static PtPlan pt_plan(long M, int H, int W, int Cin, int Cout) {
     PtPlan q;
     q.wide = false;
+    q.ks = 1;
     // the 8-wave kernel: whole 256-pixel x 128-channel tiles only, one workgroup per CU; worth it when its jobs
     // fill at least three quarters of the chip
     if (g_conv3_wide_mode != 1 && W >= 8 && Cout % WD_BN == 0 && M % WD_BM == 0 && pt_geom_ok(H, W, WD_BM)) {
@@ -737,10 +782,16 @@ static PtPlan pt_plan(long M, int H, int W, int Cout) {
     if (gx > ntiles) gx = ntiles;
     if (gx < 1) gx = 1;
     q.gx = (int)gx;
+    // at most one four-wave workgroup per CU: split K between two groups of four waves (an even number of 64-channel chunks)
+    // (measured at batch 512: the 4x4 layers 20.6 -> 18.1 us; nothing with the 128-channel tile, whose split form is at
+    // the register limit, so that one is only taken on request)
+    if (q.bm == 128 && g_conv3_ksplit_mode != 1 && (Cin / 64) % 2 == 0 &&
+        (((long)q.gx * q.gy <= 256 && q.bn == 64) || g_conv3_ksplit_mode == 2))
+        q.ks = 2;
     return q;
 }
 
-int conv3_patch_tn_rows(long M, int H, int W, int Cout) { return pt_plan(M, H, W, Cout).gx; }
+int conv3_patch_tn_rows(long M, int H, int W, int Cin, int Cout) { return pt_plan(M, H, W, Cin, Cout).gx; }
 
 int conv3_patch_tn_launch(const void* x, const void* w_packed, const float* bias, void* y, float* stat_sum, float* stat_sq,
                           int n_img, int H, int W, int Cin, int Cout, double flops, double bytes, hipStream_t s) {
@@ -748,7 +799,7 @@ int conv3_patch_tn_launch(const void* x, const void* w_packed, const float* bias
     p.A = (const bf16_t*)x; p.B = (const bf16_t*)w_packed; p.bias = bias; p.out = (bf16_t*)y;
     p.stat_sum = stat_sum; p.stat_sq = stat_sq;
     p.M = n_img * H * W; p.N = Cout; p.C = Cin; p.H = H; p.wshift = pt_ilog2(W);
-    const PtPlan plan = pt_plan(p.M, H, W, Cout);
+    const PtPlan plan = pt_plan(p.M, H, W, Cin, Cout);
     const long hw = (long)H * W;
     if (hw >= plan.bm) { p.G = 1; p.R = plan.bm / W; } else { p.G = (int)(plan.bm / hw); p.R = H; }
     p.rwshift = pt_ilog2(p.R * W);
@@ -770,14 +821,15 @@ int conv3_patch_tn_launch(const void* x, const void* w_packed, const float* bias
         VAE_LAUNCH_CHECK("conv3_wide_kernel");
         return 0;
     }
-    static char name[2][48] = {"conv3_patch_tn_kernel<64>", "conv3_patch_tn_kernel<128>"};
-    ProfScope prof(name[plan.bn == 128], flops, bytes, s);
+    static char name[4][48] = {"conv3_patch_tn_kernel<64>", "conv3_patch_tn_kernel<128>", "conv3_patch_tn_kernel<64,ksplit>",
+                               "conv3_patch_tn_kernel<128,ksplit>"};
+    ProfScope prof(name[(plan.bn == 128) + 2 * (plan.ks == 2)], flops, bytes, s);
     switch (W) {
-        case 4: pt_launch_w<4>(p, grid, plan.bn, plan.bm, s); break;
-        case 8: pt_launch_w<8>(p, grid, plan.bn, plan.bm, s); break;
-        case 16: pt_launch_w<16>(p, grid, plan.bn, plan.bm, s); break;
-        case 32: pt_launch_w<32>(p, grid, plan.bn, plan.bm, s); break;
-        default: pt_launch_w<64>(p, grid, plan.bn, plan.bm, s); break;
+        case 4: pt_launch_w<4>(p, grid, plan.bn, plan.bm, plan.ks, s); break;
+        case 8: pt_launch_w<8>(p, grid, plan.bn, plan.bm, plan.ks, s); break;
+        case 16: pt_launch_w<16>(p, grid, plan.bn, plan.bm, plan.ks, s); break;
+        case 32: pt_launch_w<32>(p, grid, plan.bn, plan.bm, plan.ks, s); break;
+        default: pt_launch_w<64>(p, grid, plan.bn, plan.bm, plan.ks, s); break;
     }
     VAE_LAUNCH_CHECK("conv3_patch_tn_kernel");
     return 0;

@@ -29,7 +29,7 @@ namespace vae {
 
 // conv3_patch_tn.hip
 bool conv3_patch_tn_ok(int n_img, int H, int W, int Cin, int Cout);
-int conv3_patch_tn_rows(long M, int H, int W, int Cout);
+int conv3_patch_tn_rows(long M, int H, int W, int Cin, int Cout);
 int conv3_patch_tn_launch(const void* x, const void* w_packed, const float* bias, void* y, float* stat_sum, float* stat_sq,
                           int n_img, int H, int W, int Cin, int Cout, double flops, double bytes, hipStream_t s);
 
@@ -465,7 +465,7 @@ extern "C" int vae_gemm_stat_rows(long M, int N) {
 
 extern "C" int vae_conv3x3_stat_rows(int n_img, int H, int W, int Cin, int Cout) {
     const long M = (long)n_img * H * W;
-    if (conv3_patch_tn_ok(n_img, H, W, Cin, Cout)) return conv3_patch_tn_rows(M, H, W, Cout);
+    if (conv3_patch_tn_ok(n_img, H, W, Cin, Cout)) return conv3_patch_tn_rows(M, H, W, Cin, Cout);
     return vae_gemm_stat_rows(M, Cout);
 }
 
