@@ -217,6 +217,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch size")
     ap.add_argument("--side-stream", action="store_true",
                     help="run the weight-gradient kernels of the backward pass on a second stream")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=INT",
+                    help="vae_set_tuning(KEY, INT) before the run (measurement aid), e.g. --tune conv3_cu_budget=128")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo to rehearse ranks that share a GPU)")
     ap.add_argument("--watchdog", type=int, default=0, help="dump every thread's stack and exit after this many seconds (0 = off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -269,6 +271,9 @@ def main():
         else:
             dist.init_process_group(args.backend)
     _lib.load()
+    for kv in args.tune:
+        k, v = kv.split("=")
+        _lib.call("vae_set_tuning", k.encode(), int(v))
 
     conf = load_config(args.config, os.path.join(ROOT, "config"))
     batch = args.batch or int(conf.batch_size)

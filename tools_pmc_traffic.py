@@ -18,9 +18,11 @@ import sys
 def bench_name(rocprof_name: str):
     """map a rocprofv3 kernel name onto the name the library's event profiler (and bench.py) uses"""
     n = rocprof_name
-    m = re.search(r"conv3_patch_tn_kernel<\d+, (\d+), \d+>", n)
+    m = re.search(r"conv3_patch_tn_kernel<\d+, (\d+), \d+(?:, (\d+))?>", n)
     if m:
-        return f"conv3_patch_tn_kernel<{m.group(1)}>"
+        return f"conv3_patch_tn_kernel<{m.group(1)}" + (",ksplit>" if m.group(2) == "2" else ">")
+    if "conv3_wide_kernel" in n:
+        return "conv3_wide_kernel"
     if "conv3_wgrad_patch_kernel" in n:
         return "conv3_wgrad_patch_kernel"
     m = re.search(r"gemm_tn_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), \d+>", n)
