@@ -55,8 +55,10 @@ int vae_prof_stop(char* names, int* launches, double* total_ms, double* flops, d
 /* Measurement aid (no counterpart in the reference): picks between kernel variants that compute the same result, so
  * that they can be timed against each other inside one process.  Keys: "conv3_wide" = 0 choose per launch (default),
  * 1 always the 4-wave conv3x3 kernel, 2 the 8-wave kernel wherever its geometry allows; "conv3_ksplit" = 0 default,
- * 1 never split K between two wave groups of a workgroup, 2 wherever the chunk count is even.  Not thread-safe: set it
- * while nothing is being launched. */
+ * 1 never split K between two wave groups of a workgroup, 2 wherever the chunk count is even; "stream_gemm" = 0 the
+ * streaming kernel for the first conv and for ConvTranspose forwards with large outputs (default), 1 the tiled GEMM
+ * always, 2 the streaming kernel wherever its geometry allows (the *_stat_rows functions follow the setting).  Not thread-safe: set it while nothing is being
+ * launched. */
 int vae_set_tuning(const char* key, int value);
 /* Diagnostic aid: device buffer (>= 128 bytes per workgroup of the launch under study) that the diagnostic kernel
  * variants selected with vae_set_tuning write cycle-counter stamps to; NULL (default) = none. */
@@ -134,12 +136,18 @@ int vae_conv3x3_gemm(const void* x, const void* w_packed, const float* bias, voi
 int vae_conv3x3_c8_gemm(const void* x8, const void* w_packed, const float* bias, void* y,
                         float* stat_sum, float* stat_sq, int n_img, int H, int W, int Cout,
                         void* stream);
+/* partial-statistics rows it writes (of Cout floats each); never more than vae_gemm_stat_rows(n*H*W, Cout) */
+int vae_conv3x3_c8_stat_rows(int n_img, int H, int W, int Cout);
 /* nn.ConvTranspose2d(Cin, Cout, 2, stride=2) forward, vae/models/vae.py:64,67,70.
  * x [n,H,W,Cin], w_packed [(kh,kw,co)][Cin], y [n,2H,2W,Cout]; stats are per GEMM column
  * (tap*Cout + co), 4*Cout of them. */
 int vae_convt2x2_fwd_gemm(const void* x, const void* w_packed, const float* bias, void* y,
                           float* stat_sum, float* stat_sq, int n_img, int H, int W, int Cin,
                           int Cout, void* stream);
+/* partial-statistics rows it writes (of 4*Cout floats each; a row may hold the sum over several taps in the columns of
+ * the first of them and zeros in the others -- the BatchNorm that follows adds the four taps of a channel anyway);
+ * never more than vae_gemm_stat_rows(n*H*W, 4*Cout) */
+int vae_convt2x2_stat_rows(int n_img, int H, int W, int Cin, int Cout);
 /* its dgrad: dy [n,2H,2W,Cout], w_packed [Cin][(kh,kw,co)], dx [n,H,W,Cin] */
 int vae_convt2x2_dgrad_gemm(const void* dy, const void* w_packed, void* dx, int n_img, int H,
                             int W, int Cin, int Cout, void* stream);

@@ -215,10 +215,11 @@ def test_convt2x2_fwd_dgrad(L, n, H, W, Ci, Co):
     b = torch.randn(Co, generator=g)
     ref = F.conv_transpose2d(x, w, b, stride=2)
     wp = w.permute(2, 3, 1, 0).contiguous().to(torch.bfloat16).to(DEV)      # [(kh,kw,co)][ci]
-    gm = L.call("vae_gemm_stat_rows", n * H * W, 4 * Co)
+    gm = L.call("vae_convt2x2_stat_rows", n, H, W, Ci, Co)
+    assert 1 <= gm <= L.call("vae_gemm_stat_rows", n * H * W, 4 * Co)
     y = torch.full((n, 2 * H, 2 * W, Co), float("nan"), device=DEV, dtype=torch.bfloat16)
-    ssum = torch.zeros(gm, 4 * Co, device=DEV)
-    ssq = torch.zeros(gm, 4 * Co, device=DEV)
+    ssum = torch.full((gm, 4 * Co), float("nan"), device=DEV)
+    ssq = torch.full((gm, 4 * Co), float("nan"), device=DEV)
     xd, bd = nhwc_bf16(x), b.to(DEV)
     L.call("vae_convt2x2_fwd_gemm", L.ptr(xd), L.ptr(wp), L.ptr(bd), L.ptr(y), L.ptr(ssum),
            L.ptr(ssq), n, H, W, Ci, Co, L.current_stream())

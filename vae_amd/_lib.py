@@ -36,6 +36,8 @@ SIGNATURES = {
     "vae_dropout_threshold": (c_uint, [c_double]),
     "vae_gemm_rows_per_block": (c_int, []),
     "vae_gemm_stat_rows": (c_int, [c_long, c_int]),
+    "vae_conv3x3_c8_stat_rows": (c_int, [c_int, c_int, c_int, c_int]),
+    "vae_convt2x2_stat_rows": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "vae_conv3x3_stat_rows": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "vae_conv3x3_gemm": (None, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "vae_convt2x2_fwd_gemm": (None, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),

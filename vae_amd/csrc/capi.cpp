@@ -60,6 +60,7 @@ void prof_end(hipStream_t s) {
 namespace vae {
 extern int g_conv3_wide_mode;
 extern int g_conv3_ksplit_mode;
+extern int g_stream_gemm_mode;
 extern unsigned long long* g_conv3_dbg;
 }
 // Diagnostic aid: a device buffer that diagnostic kernel variants write cycle stamps to (null = none).
@@ -75,6 +76,10 @@ extern "C" int vae_set_tuning(const char* key, int value) {
     }
     if (key && !strcmp(key, "conv3_ksplit")) {        // 0 auto, 1 never split K inside the workgroup, 2 wherever legal
         vae::g_conv3_ksplit_mode = value;
+        return 0;
+    }
+    if (key && !strcmp(key, "stream_gemm")) {         // 0 the streaming GEMM where it pays, 1 never (tiled GEMM), 2 wherever legal
+        vae::g_stream_gemm_mode = value;
         return 0;
     }
     vae::set_error("vae_set_tuning: unknown key '%s'", key ? key : "(null)");

@@ -33,6 +33,16 @@ int conv3_patch_tn_rows(long M, int H, int W, int Cin, int Cout);
 int conv3_patch_tn_launch(const void* x, const void* w_packed, const float* bias, void* y, float* stat_sum, float* stat_sq,
                           int n_img, int H, int W, int Cin, int Cout, double flops, double bytes, hipStream_t s);
 
+// stream_gemm.hip
+bool stream_c8_ok(int n_img, int H, int W, int Cout);
+int stream_c8_rows(int n_img, int H, int W);
+int stream_c8_launch(const void* x8, const void* w_packed, const float* bias, void* y, float* stat_sum, float* stat_sq,
+                     int n_img, int H, int W, int Cout, double flops, double bytes, hipStream_t s);
+bool stream_convt_fwd_ok(int n_img, int H, int W, int Cin, int Cout);
+int stream_convt_fwd_rows(int n_img, int H, int W, int Cin, int Cout);
+int stream_convt_fwd_launch(const void* x, const void* w_packed, const float* bias, void* y, float* stat_sum, float* stat_sq,
+                            int n_img, int H, int W, int Cin, int Cout, double flops, double bytes, hipStream_t s);
+
 enum { A_PLAIN = 0, A_CONV3 = 1, A_CONVT_DGRAD = 2, A_CONV3_C8 = 3 };
 enum { E_BF16 = 0, E_CONVT = 1, E_F32_SPLIT = 2, E_TANH_BF16 = 3, E_F32 = 4 };
 
@@ -463,6 +473,16 @@ extern "C" int vae_gemm_stat_rows(long M, int N) {
     return (int)((M + bm - 1) / bm);
 }
 
+extern "C" int vae_conv3x3_c8_stat_rows(int n_img, int H, int W, int Cout) {
+    if (stream_c8_ok(n_img, H, W, Cout)) return stream_c8_rows(n_img, H, W);
+    return vae_gemm_stat_rows((long)n_img * H * W, Cout);
+}
+
+extern "C" int vae_convt2x2_stat_rows(int n_img, int H, int W, int Cin, int Cout) {
+    if (stream_convt_fwd_ok(n_img, H, W, Cin, Cout)) return stream_convt_fwd_rows(n_img, H, W, Cin, Cout);
+    return vae_gemm_stat_rows((long)n_img * H * W, 4 * Cout);
+}
+
 extern "C" int vae_conv3x3_stat_rows(int n_img, int H, int W, int Cin, int Cout) {
     const long M = (long)n_img * H * W;
     if (conv3_patch_tn_ok(n_img, H, W, Cin, Cout)) return conv3_patch_tn_rows(M, H, W, Cin, Cout);
@@ -501,6 +521,8 @@ extern "C" int vae_conv3x3_c8_gemm(const void* x8, const void* w_packed, const f
     p.flops = 2.0 * p.M * p.N * 27.0;      // 3 real input channels x 9 taps
     p.bytes = 2.0 * ((double)p.M * 8 + (double)p.N * p.K + (double)p.M * Cout);
     if (int e = check_common(p, 64, "vae_conv3x3_c8_gemm", (double)p.M * 8)) return e;
+    if (stream_c8_ok(n_img, H, W, Cout))
+        return stream_c8_launch(x8, w_packed, bias, y, stat_sum, stat_sq, n_img, H, W, Cout, p.flops, p.bytes, (hipStream_t)stream);
     return launch_bk64<A_CONV3_C8, E_BF16>(p, (hipStream_t)stream);
 }
 
@@ -516,6 +538,9 @@ extern "C" int vae_convt2x2_fwd_gemm(const void* x, const void* w_packed, const 
     p.flops = 2.0 * p.M * p.N * p.K;
     p.bytes = 2.0 * ((double)p.M * Cin + (double)p.N * p.K + (double)p.M * p.N);
     if (int e = check_common(p, 64, "vae_convt2x2_fwd_gemm", (double)p.M * Cin)) return e;
+    if (stream_convt_fwd_ok(n_img, H, W, Cin, Cout))
+        return stream_convt_fwd_launch(x, w_packed, bias, y, stat_sum, stat_sq, n_img, H, W, Cin, Cout, p.flops, p.bytes,
+                                       (hipStream_t)stream);
     return launch_bk64<A_PLAIN, E_CONVT>(p, (hipStream_t)stream);
 }
 

@@ -367,7 +367,7 @@ static int decoder_forward(const Ctx& c, float* recon) {
         float* sq = train ? (float*)c.at(w.stat_sq) : nullptr;
         TRY(vae_convt2x2_fwd_gemm(in, c.pk_at(c.pk.ct_f[u]), c.P(P_UP3_B + 4 * u), c.at(w.yd[u]), ss, sq, d.N, hh, hh,
                                   DEC_CI[u], DEC_CO[u], c.stream));
-        TRY(bn_finalize(c, 8 + u, P_BN3_G + 4 * u, vae_gemm_stat_rows(Min, 4 * DEC_CO[u]), 4, 4.0 * (double)Min));
+        TRY(bn_finalize(c, 8 + u, P_BN3_G + 4 * u, vae_convt2x2_stat_rows(d.N, hh, hh, DEC_CI[u], DEC_CO[u]), 4, 4.0 * (double)Min));
         if (u < 2) {
             TRY(vae_bn_act_fwd(c.at(w.yd[u]), c.coef(8 + u, 0), c.coef(8 + u, 1), c.at(w.ad[u]), d.N, 2 * hh, 2 * hh,
                                DEC_CO[u], 0, 0.0, nullptr, 0, 0, 0, 0, c.stream));
@@ -390,7 +390,7 @@ static int encoder_forward(const Ctx& c, const float* x, const void* const* mask
     for (int b = 0; b < 4; ++b) {
         const int H = d.S >> b, C = ENC_C[b];
         const long M = (long)d.N * H * H;
-        const int rows_a = b == 0 ? vae_gemm_stat_rows(M, C) : vae_conv3x3_stat_rows(d.N, H, H, ENC_C[b - 1], C);
+        const int rows_a = b == 0 ? vae_conv3x3_c8_stat_rows(d.N, H, H, C) : vae_conv3x3_stat_rows(d.N, H, H, ENC_C[b - 1], C);
         const int rows = vae_conv3x3_stat_rows(d.N, H, H, C, C);
         if (b == 0)
             TRY(vae_conv3x3_c8_gemm(in, c.pk_at(c.pk.c1a), c.P(1), c.at(w.ya[0]), ss, sq, d.N, H, H, C, c.stream));
