@@ -45,6 +45,8 @@ struct PatchP {
 
 constexpr int PATCH_ROWS_MAX = 200;                   // >= 3*(64+2) = 198, multiple of 8
 constexpr int PATCH_INSTR_PER_WAVE = (PATCH_ROWS_MAX / 8 + 3) / 4;   // 7
+constexpr int WGRAD_FRAG_AHEAD = 1;                   // input fragments requested ahead of the matrix instructions (<= 3;
+                                                      // 2 and 3 measured: 2-5 % on the kernel alone, nothing in the step)
 constexpr int ROWB = 128;                             // 64 channels of bf16
 
 // XOR applied to the 16-byte chunk index of a 128-byte LDS row; `i` is the row index (dY tile) or
@@ -53,24 +55,54 @@ constexpr int ROWB = 128;                             // 64 channels of bf16
 // spread the rest over the four 32-byte slots.
 __device__ __forceinline__ int swz128(int i) { return (((i >> 1) & 1) | (((i >> 3) & 1) << 1)) << 1; }
 
-__device__ __forceinline__ bf16x8 tr_pair(const unsigned char* lo_addr, const unsigned char* hi_addr) {
-    const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((l4ptr_t)(lo_addr));
-    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((l4ptr_t)(hi_addr));
+// Transposing fragment read (two ds_read_b64_tr_b16) through inline asm.  While global->LDS copies are in flight the
+// compiler puts s_waitcnt vmcnt(0) in front of every transposing read it issues itself (the copies are pending LDS
+// writes to it, and it cannot tell the buffer being filled from the one being read): each round would wait for the
+// copies it has just requested for the NEXT round.  The compiler does not count asm loads: frag_wait<N>() is the
+// wait (at most N LDS reads still in flight) that must precede the first use of a fragment.
+__device__ __forceinline__ bf16x8 tr_pair(unsigned lo_addr, unsigned hi_addr) {
+    short4v lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3" : "=&v"(lo), "=&v"(hi) : "v"(lo_addr), "v"(hi_addr) : "memory");
     typedef __attribute__((ext_vector_type(8))) short short8v;
     const short8v v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_bit_cast(bf16x8, v);
+}
+// at most N of this wave's LDS reads still in flight; `f` is a fragment about to be used (ties the wait to it)
+template <int N>
+__device__ __forceinline__ void frag_wait(bf16x8& f) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(N) : "memory");
+}
+// the same for an n that is a constant only after unrolling
+__device__ __forceinline__ void frag_wait_n(int n, bf16x8& f) {
+    switch (n) {
+        case 0: frag_wait<0>(f); break;
+        case 2: frag_wait<2>(f); break;
+        case 4: frag_wait<4>(f); break;
+        case 6: frag_wait<6>(f); break;
+        case 8: frag_wait<8>(f); break;
+        case 10: frag_wait<10>(f); break;
+        case 12: frag_wait<12>(f); break;
+        case 14: frag_wait<14>(f); break;
+        default: frag_wait<0>(f); break;
+    }
 }
 
 // 512 threads = two groups of four waves.  Both groups hold the same 64 x 9 x 64 accumulator tile and walk the
 // workgroup's K range two K tiles at a time (group g takes tiles beg+g, beg+2+g, ...); at the end group 1 hands
 // its accumulators to group 0 through LDS, so one slab is written per workgroup: half the split-K bytes of
 // two independent 256-thread workgroups at the same number of resident waves.
+//
+// Measured and not kept: three staging buffers per group with a counted wait (a copy then has two rounds to arrive
+// instead of half a round) was 2 % slower -- a round is not waiting for memory; it is the issue of the copies
+// (~200 cycles apiece, 9 per wave) plus the fragment reads in front of 72 matrix instructions per wave.
 template <int W>
 __global__ __launch_bounds__(512, 1) void conv3_wgrad_patch_kernel(const PatchP p) {
     constexpr int W2 = W + 2;
+    constexpr int QD = WGRAD_FRAG_AHEAD;
     constexpr int P_BYTES = 64 * ROWB, Q_BYTES = PATCH_ROWS_MAX * ROWB, STAGE = P_BYTES + Q_BYTES;
     constexpr int FOLD_BYTES = 9 * 4 * 4 * 64 * 16;       // one group's accumulators: 36 float4 per lane, 4 waves
     constexpr int SMEM_BYTES = 4 * STAGE > FOLD_BYTES ? 4 * STAGE : FOLD_BYTES;
+    constexpr int QI = PATCH_INSTR_PER_WAVE;
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -82,10 +114,10 @@ __global__ __launch_bounds__(512, 1) void conv3_wgrad_patch_kernel(const PatchP 
     // ---- per-lane patch staging state (the lane's patch rows never change) -------------
     // packed: bits 0-7 pixel offset inside the tile + 128, 8-15 image-row offset r + 1, 16-18 source chunk,
     // bit 24 "row holds a pixel" (else padding: left/right halo or past the patch)
-    int q_st[PATCH_INSTR_PER_WAVE];
+    int q_st[QI];
     const int ninstr = (p.PR + 7) >> 3;
 #pragma unroll
-    for (int i = 0; i < PATCH_INSTR_PER_WAVE; ++i) {
+    for (int i = 0; i < QI; ++i) {
         const int prow = (wave + 4 * i) * 8 + (lane >> 3);
         const int per = (p.R + 2) * W2;
         const int g = prow / per, rem = prow - g * per;
@@ -122,7 +154,7 @@ __global__ __launch_bounds__(512, 1) void conv3_wgrad_patch_kernel(const PatchP 
         const unsigned rowb = (unsigned)p.Ci * 2;
         const int h0 = p.G == 1 ? ((k0 >> p.wshift) & (p.H - 1)) : 0;
 #pragma unroll
-        for (int i = 0; i < PATCH_INSTR_PER_WAVE; ++i) {
+        for (int i = 0; i < QI; ++i) {
             if (wave + 4 * i < ninstr) {     // wave-uniform
                 int st = q_st[i];
                 asm volatile("" : "+v"(st));
@@ -165,7 +197,8 @@ __global__ __launch_bounds__(512, 1) void conv3_wgrad_patch_kernel(const PatchP 
             p_addr[kk][hl] = row * ROWB + (((((t16 & 3) >> 1)) ^ swz128(row)) << 4 | within);
         }
 
-    auto q_frag = [&](const unsigned char* sbase, int kk, int t) -> bf16x8 {
+    const unsigned smem_u = (unsigned)(size_t)(lptr_t)smem;      // LDS byte address of the staging area
+    auto q_frag = [&](unsigned sbase, int kk, int t) -> bf16x8 {
         const int dh = t / 3, dw = t % 3;      // 0..2
         return tr_pair(sbase + q_addr[kk][0][dw] + dh * W2 * ROWB, sbase + q_addr[kk][1][dw] + dh * W2 * ROWB);
     };
@@ -174,16 +207,20 @@ __global__ __launch_bounds__(512, 1) void conv3_wgrad_patch_kernel(const PatchP 
     const int niter = (min(split * p.kps + p.kps, p.ktiles) - split * p.kps + 1) >> 1;   // same for both groups
     for (int it = 0; it < niter; ++it) {
         const int kt = kt_beg + 2 * it;
+        const int buf = it & 1, nbuf = buf ^ 1;
+        // not __syncthreads(): nothing but the copies of this round is in flight here, and the fragment reads below are
+        // asm, so no fence is needed beyond the two waits
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        // The copies for the next round cost the issuing wave ~150 cycles apiece (9 per wave).  Each SIMD holds one wave
+        barrier_keep_copies();
+        // The copies for the next round cost the issuing wave ~200 cycles apiece (9 per wave).  Each SIMD holds one wave
         // of either group: group 0 issues its copies now, group 1 after its first 36 MFMAs, so that one group's matrix
         // instructions run under the other's copy issue instead of all eight waves issuing, then all computing.
-        if (grp == 0 && kt + 2 < kt_end) stage((it + 1) & 1, kt + 2);
-        if (kt >= kt_end) continue;                       // odd tile count: group 1 idles in the last round
-        const unsigned char* sbase = smem + (2 * (it & 1) + grp) * STAGE;
+        if (grp == 0 && kt + 2 < kt_end) stage(nbuf, kt + 2);
+        const unsigned sbase = smem_u + (unsigned)((2 * buf + grp) * STAGE);
+        const bool live = kt < kt_end;                    // odd tile count: group 1 only copies in the last round
         // dY fragments of both halves of the tile: the second half's are requested while the first half's last taps
-        // run, so only the first read of a round exposes its LDS latency
+        // run, so only the first read of a round exposes its LDS latency.  LDS reads complete in order: a fragment is
+        // ready once no more reads are in flight than were issued after it.
         bf16x8 pb[2][4];
         auto load_pb = [&](int kk) {
 #pragma unroll
@@ -196,24 +233,35 @@ __global__ __launch_bounds__(512, 1) void conv3_wgrad_patch_kernel(const PatchP 
                 pb[kk][j] = tr_pair(sbase + alo, sbase + ahi);
             }
         };
-        load_pb(0);
+        // The 18 (half tile, tap) steps of a round are 4 MFMAs = 64 cycles each, less than an LDS round trip under load:
+        // the input fragment of step s + QD is requested before step s runs.  LDS reads complete in order, so the
+        // fragment of step s is ready once no more reads are in flight than were issued after it: two per later
+        // fragment, and the eight of load_pb(1), which goes out QD steps before tap 6 of the first half so that it is
+        // older than every fragment of the second half.
+        bf16x8 qa[QD + 1];
+        if (live) {
+            load_pb(0);
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 qa[2];
-            qa[0] = q_frag(sbase, kk, 0);
+            for (int d = 0; d < QD; ++d) qa[d] = q_frag(sbase, d / 9, d % 9);
+        }
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                if (t + 1 < 9) qa[(t + 1) & 1] = q_frag(sbase, kk, t + 1);
-                if (kk == 0 && t == 6) load_pb(1);
+        for (int st = 0; st < 18; ++st) {
+            if (live) {
+                const int kk = st / 9, t = st % 9;
+                if (st + QD < 18) qa[(st + QD) % (QD + 1)] = q_frag(sbase, (st + QD) / 9, (st + QD) % 9);
+                if (st == 6 - QD) load_pb(1);
+                const int later = 17 - st < QD ? 17 - st : QD;
+                frag_wait_n(2 * later + (st >= 6 - QD && st <= 6 ? 8 : 0), qa[st % (QD + 1)]);
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[t & 1], pb[kk][j], acc[t][j], 0, 0, 0);
+                    acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[st % (QD + 1)], pb[kk][j], acc[t][j], 0, 0, 0);
                 __builtin_amdgcn_s_setprio(0);
             }
-            if (kk == 0 && grp == 1 && kt + 2 < kt_end) stage((it + 1) & 1, kt + 2);
+            if (st == 8 && grp == 1 && kt + 2 < kt_end) stage(nbuf, kt + 2);
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // The two groups hold partial sums of the same tile.  They swap halves through LDS (the staging buffers are
     // dead): group 0 ends up with the complete taps 0-4, group 1 with taps 5-8, and each stores its share of the
@@ -279,8 +327,9 @@ extern "C" int vae_conv3_wgrad_patch_ok(int H, int W, int Cin, int Cout) {
     if (ilog2x(H) < 0 || ilog2x(W) < 0 || W < 4 || W > 64) return 0;
     if (Cin % 64 || Cout % 64) return 0;
     const long hw = (long)H * W;
-    if (hw >= 64) return 64 % W == 0 ? 1 : 0;
-    return 64 % hw == 0 ? 1 : 0;
+    if (hw >= 64 ? 64 % W != 0 : 64 % hw != 0) return 0;
+    const int G = hw >= 64 ? 1 : (int)(64 / hw), R = hw >= 64 ? 64 / W : H;
+    return G * (R + 2) * (W + 2) <= PATCH_ROWS_MAX ? 1 : 0;      // the patch of a K tile must fit its LDS buffer
 }
 
 extern "C" int vae_conv3_wgrad_patch_ksplit(int n_img, int H, int W, int Cin, int Cout) {
