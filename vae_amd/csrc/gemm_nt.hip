@@ -50,21 +50,30 @@ __device__ __forceinline__ int tr_swz(int row) {
     return (((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1;
 }
 
+// The two transposing reads of a fragment go through inline asm: while global->LDS copies are in flight the compiler
+// puts s_waitcnt vmcnt(0) in front of every ds_read_b64_tr it issues itself (the copies are pending LDS writes to it, and
+// it cannot tell the ring slot being filled from the one being read), which drains the whole ring at every K-step.
+// The compiler does not count asm loads: frags_wait<N>() (at most N LDS reads still in flight) must precede the first
+// use of a fragment.  `base` is an LDS byte address.
 template <int ROWB>
-__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* base, int k0, int col0, int lane) {
+__device__ __forceinline__ bf16x8 tr_frag(unsigned base, int k0, int col0, int lane) {
     // lanes 16g..16g+15 fetch k rows k0+8g .. k0+8g+7 of columns col0..col0+15, transposed:
     // lane (l&15) receives column col0+(l&15), elements = 8 consecutive k.
     const int g = lane >> 4, t = lane & 15;
     const int row = k0 + 8 * g + (t >> 2);
     const int off = (col0 + 4 * (t & 3)) * 2;            // byte offset inside the row
     const int chunk = off >> 4, within = off & 15;
-    const unsigned char* a = base + row * ROWB + (((chunk ^ tr_swz<ROWB>(row)) << 4) | within);
-    const unsigned char* b = base + (row + 4) * ROWB + (((chunk ^ tr_swz<ROWB>(row + 4)) << 4) | within);
-    const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((l4ptr_t)(a));
-    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((l4ptr_t)(b));
+    const unsigned a = base + row * ROWB + (((chunk ^ tr_swz<ROWB>(row)) << 4) | within);
+    const unsigned b = base + (row + 4) * ROWB + (((chunk ^ tr_swz<ROWB>(row + 4)) << 4) | within);
+    short4v lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3" : "=&v"(lo), "=&v"(hi) : "v"(a), "v"(b) : "memory");
     typedef __attribute__((ext_vector_type(8))) short short8v;
     const short8v v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_bit_cast(bf16x8, v);
+}
+template <int N>
+__device__ __forceinline__ void frags_wait(bf16x8& f) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(N) : "memory");
 }
 
 // s_waitcnt vmcnt(groups * PER) for a wave-uniform runtime group count in [0, 3]
@@ -178,23 +187,38 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmNT p) {
         nt_wait_groups<P_INSTR + Q_INSTR>(min(NST - 2, nk - 1 - ks));      // K-step ks has landed
         barrier_keep_copies();            // not __syncthreads(): its fence would drain the younger copies too
         if (ks + NST - 1 < nk) stage(slot == 0 ? NST - 1 : slot - 1, kbeg + (ks + NST - 1) * BK);   // the slot read in K-step ks - 1
-        const unsigned char* pbase = smem + slot * STAGE;
+        const unsigned pbase = (unsigned)(size_t)(lptr_t)smem + (unsigned)(slot * STAGE);     // LDS byte addresses
         slot = slot + 1 == NST ? 0 : slot + 1;
-        const unsigned char* qbase = pbase + P_BYTES;
+        const unsigned qbase = pbase + P_BYTES;
+        // the fragments of the second half of the K-step are requested before the first half is multiplied; LDS reads
+        // complete in order, so a half is ready once no more reads are in flight than were issued after it
+        bf16x8 qa[2][FN], pb[2][FM];
+        auto load_half = [&](int kk) {
+#pragma unroll
+            for (int i = 0; i < FN; ++i) qa[kk][i] = tr_frag<ROWQ>(qbase, kk * 32, wn * TNw + i * 16, lane);
+#pragma unroll
+            for (int j = 0; j < FM; ++j) pb[kk][j] = tr_frag<ROWP>(pbase, kk * 32, wm * TMw + j * 16, lane);
+        };
+        load_half(0);
 #pragma unroll
         for (int kk = 0; kk < BK / 32; ++kk) {
-            bf16x8 qa[FN], pb[FM];
+            constexpr int NEWER = 2 * (FN + FM) < 15 ? 2 * (FN + FM) : 15;
+            if (kk + 1 < BK / 32) {
+                load_half(kk + 1);
 #pragma unroll
-            for (int i = 0; i < FN; ++i) qa[i] = tr_frag<ROWQ>(qbase, kk * 32, wn * TNw + i * 16, lane);
+                for (int i = 0; i < FN; ++i) frags_wait<NEWER>(qa[kk][i]);
+            } else {
 #pragma unroll
-            for (int j = 0; j < FM; ++j) pb[j] = tr_frag<ROWP>(pbase, kk * 32, wm * TMw + j * 16, lane);
+                for (int i = 0; i < FN; ++i) frags_wait<0>(qa[kk][i]);
+            }
 #pragma unroll
             for (int i = 0; i < FN; ++i)
 #pragma unroll
                 for (int j = 0; j < FM; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[i], pb[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[kk][i], pb[kk][j], acc[i][j], 0, 0, 0);
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // acc[i][j][r]: n = n0 + wn*TNw + i*16 + (lane>>4)*4 + r ; m = m0 + wm*TMw + j*16 + (lane&15)
     float* out = p.slab + (long)split * p.slab_stride;
