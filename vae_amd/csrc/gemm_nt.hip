@@ -268,38 +268,46 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
 struct Limits {
     int l0, l1, l2, l3;
 };
+// SG split groups x 256/SG float4 columns per workgroup.  A job with many splits and few elements (the 64->64 conv:
+// 256 slabs of 36 864 floats) is a chain of dependent loads per thread: with 4 groups that was 64 slabs per thread on
+// 144 workgroups -- the long pole of its launch -- with 16 groups it is 16 slabs per thread (4 loads in flight) on 576.
+template <int SG>
 __device__ __forceinline__ void reduce_slabs_scatter_body(const float* __restrict__ slab, int nsplit, long slab_stride,
                                                           float* __restrict__ out, long n, const IndexMap& mp,
-                                                          const Limits& lim, int accumulate, float4 (*red)[64]) {
-    // 64 lanes x 16 bytes of consecutive slab elements, 4 split groups per workgroup (n % 4 == 0)
-    const int ql = threadIdx.x & 63, sg = threadIdx.x >> 6;
+                                                          const Limits& lim, int accumulate, float4* red) {
+    constexpr int CW = 256 / SG;
+    const int ql = threadIdx.x % CW, sg = threadIdx.x / CW;
     const long n4 = n >> 2;
-    for (long b = (long)blockIdx.x * 64; b < n4; b += (long)gridDim.x * 64) {
+    const long st4 = slab_stride >> 2;
+    for (long b = (long)blockIdx.x * CW; b < n4; b += (long)gridDim.x * CW) {
         const long q4 = b + ql;
-        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
         if (q4 < n4) {
             const float4* src = (const float4*)slab + q4;
             int k = sg;
-            for (; k + 4 < nsplit; k += 8) {
-                const float4 u = src[(long)k * (slab_stride >> 2)], w = src[(long)(k + 4) * (slab_stride >> 2)];
+            for (; k + 3 * SG < nsplit; k += 4 * SG) {
+                const float4 u = src[(long)k * st4], v = src[(long)(k + SG) * st4], w = src[(long)(k + 2 * SG) * st4],
+                             x = src[(long)(k + 3 * SG) * st4];
                 a0.x += u.x; a0.y += u.y; a0.z += u.z; a0.w += u.w;
-                a1.x += w.x; a1.y += w.y; a1.z += w.z; a1.w += w.w;
+                a1.x += v.x; a1.y += v.y; a1.z += v.z; a1.w += v.w;
+                a2.x += w.x; a2.y += w.y; a2.z += w.z; a2.w += w.w;
+                a3.x += x.x; a3.y += x.y; a3.z += x.z; a3.w += x.w;
             }
-            if (k < nsplit) {
-                const float4 u = src[(long)k * (slab_stride >> 2)];
+            for (; k < nsplit; k += SG) {
+                const float4 u = src[(long)k * st4];
                 a0.x += u.x; a0.y += u.y; a0.z += u.z; a0.w += u.w;
             }
         }
-        red[sg][ql] = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
+        red[sg * CW + ql] = make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y),
+                                        (a0.z + a1.z) + (a2.z + a3.z), (a0.w + a1.w) + (a2.w + a3.w));
         __syncthreads();
-        // thread (sg, ql) finishes element sg of lane ql's float4
-        if (q4 < n4) {
-            const float* r0 = (const float*)&red[0][ql];
-            const float* r1 = (const float*)&red[1][ql];
-            const float* r2 = (const float*)&red[2][ql];
-            const float* r3 = (const float*)&red[3][ql];
-            const float s = (r0[sg] + r1[sg]) + (r2[sg] + r3[sg]);
-            const long q = (q4 << 2) + sg;
+        // thread t < 4 * CW finishes element t & 3 of column t >> 2: the groups are added in a fixed order
+        const int cq = threadIdx.x >> 2, el = threadIdx.x & 3;
+        if (threadIdx.x < 4 * CW && b + cq < n4) {
+            float s = 0.f;
+#pragma unroll
+            for (int g = 0; g < SG; ++g) s += ((const float*)&red[g * CW + cq])[el];
+            const long q = ((b + cq) << 2) + el;
             const int i3 = (int)(q % mp.d3);
             long t = q / mp.d3;
             const int i2 = (int)(t % mp.d2);
@@ -315,11 +323,14 @@ __device__ __forceinline__ void reduce_slabs_scatter_body(const float* __restric
     }
 }
 
+static inline bool reduce_wide_groups(int nsplit) { return nsplit >= 64; }
+
 __global__ __launch_bounds__(256) void reduce_slabs_scatter_kernel(const float* __restrict__ slab, int nsplit,
                                                                    long slab_stride, float* __restrict__ out, long n,
-                                                                   IndexMap mp, Limits lim, int accumulate) {
-    __shared__ float4 red[4][64];
-    reduce_slabs_scatter_body(slab, nsplit, slab_stride, out, n, mp, lim, accumulate, red);
+                                                                   IndexMap mp, Limits lim, int accumulate, int sg16) {
+    __shared__ float4 red[256];
+    if (sg16) reduce_slabs_scatter_body<16>(slab, nsplit, slab_stride, out, n, mp, lim, accumulate, red);
+    else reduce_slabs_scatter_body<4>(slab, nsplit, slab_stride, out, n, mp, lim, accumulate, red);
 }
 
 // several folds in one launch: blockIdx.y selects the job
@@ -329,16 +340,17 @@ struct ReduceJob {
     long slab_stride, n;
     IndexMap mp;
     Limits lim;
-    int nsplit, accumulate;
+    int nsplit, accumulate, sg16;
 };
 struct ReduceJobs {
     ReduceJob j[VAE_MAX_REDUCE_JOBS];
 };
 __global__ __launch_bounds__(256) void multi_reduce_slabs_scatter_kernel(const ReduceJobs jobs) {
-    __shared__ float4 red[4][64];
+    __shared__ float4 red[256];
     const ReduceJob& jb = jobs.j[blockIdx.y];
-    if ((long)blockIdx.x * 64 >= (jb.n >> 2)) return;      // whole workgroup: no barrier is skipped by part of it
-    reduce_slabs_scatter_body(jb.slab, jb.nsplit, jb.slab_stride, jb.out, jb.n, jb.mp, jb.lim, jb.accumulate, red);
+    if ((long)blockIdx.x * (jb.sg16 ? 16 : 64) >= (jb.n >> 2)) return;      // whole workgroup: no barrier is skipped by part of it
+    if (jb.sg16) reduce_slabs_scatter_body<16>(jb.slab, jb.nsplit, jb.slab_stride, jb.out, jb.n, jb.mp, jb.lim, jb.accumulate, red);
+    else reduce_slabs_scatter_body<4>(jb.slab, jb.nsplit, jb.slab_stride, jb.out, jb.n, jb.mp, jb.lim, jb.accumulate, red);
 }
 
 // Every weight tensor of the model repacked in ONE launch: blockIdx.y selects the job.  A job is walked in the
@@ -626,10 +638,12 @@ extern "C" int vae_reduce_slabs_scatter(const float* slab, int nsplit, long slab
     const long n = dims4[0] * dims4[1] * dims4[2] * dims4[3];
     VAE_CHECK(n % 4 == 0 && slab_stride % 4 == 0 && slab_base % 4 == 0 && ((uintptr_t)slab & 15) == 0,
               "vae_reduce_slabs_scatter: element count, slab stride and base must be multiples of 4 (16-byte rows)");
-    const int grid = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+    const int sg16 = reduce_wide_groups(nsplit);
+    const long cw = sg16 ? 16 : 64, blocks = (n / 4 + cw - 1) / cw;
+    const int grid = (int)(blocks > 2048 ? 2048 : blocks);
     ProfScope prof("reduce_slabs_scatter_kernel", 0.0, 4.0 * n * (nsplit + 1), (hipStream_t)stream);
     hipLaunchKernelGGL(reduce_slabs_scatter_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, slab + slab_base,
-                       nsplit, slab_stride, out, n, mp, lim, accumulate);
+                       nsplit, slab_stride, out, n, mp, lim, accumulate, sg16);
     VAE_LAUNCH_CHECK("reduce_slabs_scatter_kernel");
     return 0;
 }
@@ -650,7 +664,9 @@ extern "C" int vae_multi_reduce_slabs_scatter(const vae_reduce_job* jobs, int nj
                   "vae_multi_reduce_slabs_scatter: job %d: element count, slab stride and base must be multiples of 4", i);
         rj.j[i].slab = q.slab + q.slab_base; rj.j[i].out = q.out; rj.j[i].slab_stride = q.slab_stride; rj.j[i].n = n;
         rj.j[i].nsplit = q.nsplit; rj.j[i].accumulate = q.accumulate;
-        const long blocks = (n / 4 + 63) / 64;
+        rj.j[i].sg16 = reduce_wide_groups(q.nsplit);
+        const long cw = rj.j[i].sg16 ? 16 : 64;
+        const long blocks = (n / 4 + cw - 1) / cw;
         if (blocks > max_blocks) max_blocks = blocks;
         bytes += 4.0 * n * (q.nsplit + 1);
     }
