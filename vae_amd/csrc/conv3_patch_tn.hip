@@ -72,6 +72,16 @@ __device__ __forceinline__ float pt_row16_sum(float v) {
     return v;
 }
 
+// XOR applied to the 16-byte chunk index of a patch row; a function of the patch COLUMN only, so that a vertical tap
+// shift is an immediate offset.  ds_read_b128 is served in four groups of 16 lanes that are NOT contiguous -- lanes
+// {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32 -- i.e. a group holds pixels 0-3 and 12-15 of a fragment
+// with one chunk and pixels 4-11 with the next.  Bit 0 of the chunk therefore already separates the two pixel sets,
+// the row parity (rows are 128 B, the bank row 256 B) separates odd from even pixels, and bits 1-2 must be distinct on
+// columns {c, c+2, c+12, c+14} and on {c+4, .., c+10}: (col >> 1) & 3 is.  (The earlier (col >> 1) & 7 also flipped bit
+// 0 and collided with the group structure: 40-50 % of the LDS cycles of these reads were bank conflicts by the
+// hardware counter.)  4-wide images put four image rows in a fragment and keep 2-way conflicts on half the reads.
+__device__ __forceinline__ int pt_swz(int col) { return ((col >> 1) & 3) << 1; }
+
 // workgroups that share a CU: three of the 64-channel form (a third of the LDS and at most 168 VGPRs each), else two
 constexpr int pt_wgs(int W, int BN, int BM = 128) { return BN == 64 && BM == 128 && W != 4 ? 3 : 2; }
 
@@ -128,7 +138,7 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 2 : pt_wgs(W, BN, PT_BM)) void 
         const int g = p.G == 1 ? 0 : (int)(((float)prow + 0.5f) * p.inv_per);
         const int rem = prow - g * per;
         const int rr = (int)(((float)rem + 0.5f) * (1.0f / W2)), xx = rem - rr * W2;
-        int st = ((lane & 7) ^ ((xx >> 1) & 7)) << 18;
+        int st = ((lane & 7) ^ pt_swz(xx)) << 18;
         if (prow < p.PR && xx >= 1 && xx <= W) st |= ((g * p.R + (rr - 1)) * W + (xx - 1) + 256) | (rr << 10) | (1 << 24);
         q_st[i] = st;
     }
@@ -184,7 +194,7 @@ __global__ __launch_bounds__(256 * KS, KS == 2 ? 2 : pt_wgs(W, BN, PT_BM)) void 
         const int prow = (g * (p.R + 2) + r) * W2 + x + 1;            // the pixel one image row up
 #pragma unroll
         for (int d = 0; d < 3; ++d)
-            a_addr[i][d] = (prow + d - 1) * PT_ROWB + (((lane >> 4) ^ (((x + d) >> 1) & 7)) << 4);
+            a_addr[i][d] = (prow + d - 1) * PT_ROWB + (((lane >> 4) ^ pt_swz(x + d)) << 4);
     }
     int b_addr[FN];
 #pragma unroll
@@ -493,7 +503,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wide_kernel(const PatchTN p) {
         const int g = p.G == 1 ? 0 : (int)(((float)prow + 0.5f) * p.inv_per);
         const int rem = prow - g * per;
         const int rr = (int)(((float)rem + 0.5f) * (1.0f / W2)), xx = rem - rr * W2;
-        int st = ((lane & 7) ^ ((xx >> 1) & 7)) << 18;
+        int st = ((lane & 7) ^ pt_swz(xx)) << 18;
         if (prow < p.PR && xx >= 1 && xx <= W) st |= ((g * p.R + (rr - 1)) * W + (xx - 1) + 256) | (rr << 10) | (1 << 24);
         q_st[i] = st;
     }
@@ -527,7 +537,7 @@ __global__ __launch_bounds__(512, 2) void conv3_wide_kernel(const PatchTN p) {
         const int prow = (g * (p.R + 2) + r) * W2 + x + 1;            // the pixel one image row up
 #pragma unroll
         for (int d = 0; d < 3; ++d)
-            a_addr[i][d] = (prow + d - 1) * PT_ROWB + (((lane / F) ^ (((x + d) >> 1) & 7)) << 4);
+            a_addr[i][d] = (prow + d - 1) * PT_ROWB + (((lane / F) ^ pt_swz(x + d)) << 4);
     }
     int b_addr[NF];
 #pragma unroll
