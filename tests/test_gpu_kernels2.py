@@ -111,10 +111,22 @@ def test_conv3x3_wgrad(L, n, H, W, Ci, Co):
 
 @pytest.mark.parametrize("n,H,W,Ci,Co,ns", [
     (5, 4, 4, 256, 64, 0), (3, 4, 4, 64, 64, 1), (3, 8, 8, 128, 64, 0), (2, 16, 16, 64, 128, 2), (2, 32, 32, 64, 64, 0),
-    (1, 64, 64, 64, 64, 7), (9, 2, 4, 64, 64, 0), (1, 16, 8, 64, 64, 0), (64, 8, 8, 128, 256, 0)])
-def test_conv3x3_wgrad_patch(L, n, H, W, Ci, Co, ns):
+    (1, 64, 64, 64, 64, 7), (9, 2, 4, 64, 64, 0), (1, 16, 8, 64, 64, 0), (64, 8, 8, 128, 256, 0),
+    # one, two and three K tiles per workgroup (the shortest pipelines of the copying / computing form), an odd count
+    (1, 8, 8, 64, 64, 1), (2, 8, 8, 64, 64, 1), (3, 8, 8, 64, 64, 1), (7, 16, 16, 64, 64, 4)])
+@pytest.mark.parametrize("form", [2, 1])
+def test_conv3x3_wgrad_patch(L, n, H, W, Ci, Co, ns, form):
     """nine-taps-per-workgroup kernel == autograd's Conv2d weight gradient (images smaller than, equal to and
-    larger than a 64-pixel K tile, ragged last tile, forced and suggested K splits)"""
+    larger than a 64-pixel K tile, ragged last tile, forced and suggested K splits), in both of its forms: every wave
+    copies and computes (2), separate copying and computing waves (1)"""
+    L.call("vae_set_tuning", b"wgrad_pc", form)
+    try:
+        _check_conv3x3_wgrad_patch(L, n, H, W, Ci, Co, ns)
+    finally:
+        L.call("vae_set_tuning", b"wgrad_pc", 0)
+
+
+def _check_conv3x3_wgrad_patch(L, n, H, W, Ci, Co, ns):
     assert L.call("vae_conv3_wgrad_patch_ok", H, W, Ci, Co) == 1
     g = torch.Generator().manual_seed(n + H + Ci)
     x = bf(torch.randn(n, Ci, H, W, generator=g))

@@ -67,6 +67,16 @@ __device__ __forceinline__ bf16x8 tr_pair(unsigned lo_addr, unsigned hi_addr) {
     const short8v v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_bit_cast(bf16x8, v);
 }
+// the same with an immediate byte offset (a vertical tap shift costs no address arithmetic)
+template <int OFF>
+__device__ __forceinline__ bf16x8 tr_pair_off(unsigned lo_addr, unsigned hi_addr) {
+    short4v lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%4\n\tds_read_b64_tr_b16 %1, %3 offset:%4"
+                 : "=&v"(lo), "=&v"(hi) : "v"(lo_addr), "v"(hi_addr), "n"(OFF) : "memory");
+    typedef __attribute__((ext_vector_type(8))) short short8v;
+    const short8v v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
 // at most N of this wave's LDS reads still in flight; `f` is a fragment about to be used (ties the wait to it)
 template <int N>
 __device__ __forceinline__ void frag_wait(bf16x8& f) {
@@ -83,6 +93,7 @@ __device__ __forceinline__ void frag_wait_n(int n, bf16x8& f) {
         case 10: frag_wait<10>(f); break;
         case 12: frag_wait<12>(f); break;
         case 14: frag_wait<14>(f); break;
+        case 15: frag_wait<15>(f); break;
         default: frag_wait<0>(f); break;
     }
 }
@@ -310,6 +321,244 @@ __global__ __launch_bounds__(512, 1) void conv3_wgrad_patch_kernel(const PatchP 
     }
 }
 
+
+// Producer / consumer form of the same kernel.  In the form above every wave issues its share of the copies AND
+// runs its share of the matrix instructions, one after the other: a CU takes in only ~70 GB/s through global->LDS
+// copies, a 1 KB copy holds the issuing wave for ~100-200 cycles, and with two waves per SIMD doing the same work the
+// copy issue (0.9 us per round), the fragment reads and the MFMAs (0.55 us) simply add up.  Here waves 4-7 only copy
+// (a ring of four single-tile stages, three tiles ahead, counted wait) and waves 0-3 only compute, one 64-pixel K tile
+// per barrier: ONE accumulator set per workgroup (no hand-over between groups), and the copies of tile r + 3 run under
+// the matrix instructions of tile r.
+template <int W>
+__global__ __launch_bounds__(512, 1) void conv3_wgrad_pc_kernel(const PatchP p) {
+    constexpr int W2 = W + 2;
+    constexpr int QD = 2;     // input fragments requested ahead (4 measured: 10 % slower)
+    constexpr int P_BYTES = 64 * ROWB, Q_BYTES = PATCH_ROWS_MAX * ROWB, STAGE = P_BYTES + Q_BYTES;
+    constexpr int DUMMY = 4 * STAGE, SMEM_BYTES = DUMMY + 1024;
+    constexpr int QI = PATCH_INSTR_PER_WAVE;
+    static_assert(SMEM_BYTES <= 160 * 1024 && 4 * 64 * 16 * 16 <= DUMMY, "LDS");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int role = __builtin_amdgcn_readfirstlane(tid >> 8), wave = __builtin_amdgcn_readfirstlane((tid >> 6) & 3);   // 0: compute, 1: copy
+    const int n0 = blockIdx.x * 64, m0 = blockIdx.y * 64, split = blockIdx.z;
+    const int kt_beg = split * p.kps, kt_end = min(kt_beg + p.kps, p.ktiles);
+    const int ntile = kt_end - kt_beg;
+
+    int q_st[QI];
+    const int ninstr = (p.PR + 7) >> 3;
+    const int nq = max((ninstr + 3) >> 2, 4);       // patch copies per producer wave and tile, the same for all four
+#pragma unroll
+    for (int i = 0; i < QI; ++i) {
+        const int prow = (wave + 4 * i) * 8 + (lane >> 3);
+        const int per = (p.R + 2) * W2;
+        const int g = prow / per, rem = prow - g * per;
+        const int rr = rem / W2, xx = rem - rr * W2;
+        int st = ((lane & 7) ^ swz128(xx)) << 16;
+        if (prow < p.PR && xx >= 1 && xx <= W) st |= ((g * p.R + (rr - 1)) * W + (xx - 1) + 128) | (rr << 8) | (1 << 24);
+        q_st[i] = st;
+    }
+    const int p_row0 = wave * 8 + (lane >> 3);
+    const int p_ch0 = (lane & 7) ^ swz128(p_row0);
+    constexpr unsigned OOB = 0xFFFFFFFFu;
+    const __amdgpu_buffer_rsrc_t p_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)p.P, 0, (int)((unsigned)p.Ktot * (unsigned)p.Co * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t q_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)p.Q, 0, (int)((unsigned)p.Ktot * (unsigned)p.Ci * 2u), 0x00020000);
+    // exactly 2 + nq copies per producer wave and call (the counted wait depends on it): pieces past the patch and
+    // tiles past the range are zero fills (into the dummy kilobyte / the stage)
+    auto stage = [&](int buf, int kt) {
+        unsigned char* pbase = smem + buf * STAGE;
+        unsigned char* qbase = pbase + P_BYTES;
+        const int k0 = kt * 64;
+        const int ktot = kt < kt_end ? p.Ktot : 0;      // wave-uniform
+        {
+            int ra = p_row0, ca = p_ch0;
+            asm volatile("" : "+v"(ra), "+v"(ca));
+            const int ka = k0 + ra, kb = ka + 32;       // rows 32 apart agree in both swizzle bits
+            const unsigned prow = (unsigned)p.Co * 2;
+            const unsigned oa = ka < ktot ? (unsigned)ka * prow + (unsigned)(m0 * 2 + ca * 16) : OOB;
+            const unsigned ob = kb < ktot ? (unsigned)kb * prow + (unsigned)(m0 * 2 + ca * 16) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(p_rsrc, (lptr_t)(pbase + wave * 1024), 16, (int)oa, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(p_rsrc, (lptr_t)(pbase + (wave + 4) * 1024), 16, (int)ob, 0, 0, 0);
+        }
+        const unsigned rowb = (unsigned)p.Ci * 2;
+        const int h0 = p.G == 1 ? ((k0 >> p.wshift) & (p.H - 1)) : 0;
+#pragma unroll
+        for (int i = 0; i < QI; ++i) {
+            if (i < nq) {     // uniform over the workgroup
+                const bool real = wave + 4 * i < ninstr;      // wave-uniform
+                int st = q_st[i];
+                asm volatile("" : "+v"(st));
+                const int k = k0 + (st & 255) - 128, r = ((st >> 8) & 255) - 1;
+                unsigned off = OOB;
+                if (real && (st >> 24) && (unsigned)(h0 + r) < (unsigned)p.H && (unsigned)k < (unsigned)ktot)
+                    off = (unsigned)k * rowb + (unsigned)(n0 * 2 + ((st >> 12) & 0x70));
+                unsigned char* dst = real ? qbase + (wave + 4 * i) * 1024 : smem + DUMMY;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(q_rsrc, (lptr_t)dst, 16, (int)off, 0, 0, 0);
+            }
+        }
+    };
+    // at most the two youngest tiles' copies of this wave still in flight
+    auto wait_two_tiles = [&]() {
+        if (nq == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (nq == 5) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+        else if (nq == 6) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+    };
+
+    f32x4 acc[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int t16 = lane & 15;
+    int q_addr[2][2][3];       // [kk][lo/hi][dw + 1], tap row dh = -1
+    int p_addr[2][2];          // [kk][lo/hi] for output-channel fragment j = 0
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int hl = 0; hl < 2; ++hl) {
+            const int k = kk * 32 + 8 * (lane >> 4) + 4 * hl;             // first pixel of the quad
+            const int g = k >> p.rwshift, kr = k & ((1 << p.rwshift) - 1);
+            const int r = kr >> p.wshift, x = (kr & (W - 1)) + (t16 >> 2);
+            const int prow = (g * (p.R + 2) + r) * W2 + x + 1;            // patch row of the pixel one image row up
+            const int chunk = wave * 2 + ((t16 & 3) >> 1), within = (t16 & 1) * 8;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const int xx = x + d;
+                q_addr[kk][hl][d] = P_BYTES + (prow + d - 1) * ROWB + (((chunk ^ swz128(xx)) << 4) | within);
+            }
+            const int row = k + (t16 >> 2);
+            p_addr[kk][hl] = row * ROWB + (((((t16 & 3) >> 1)) ^ swz128(row)) << 4 | within);
+        }
+    const unsigned smem_u = (unsigned)(size_t)(lptr_t)smem;
+    // The two roles run separate loops with the same number of barriers.  A round is two K tiles (stages 2 (q & 1) and
+    // 2 (q & 1) + 1): after barrier q the copying waves refill the pair that round q - 1 used with the tiles of round
+    // q + 1, which then have a whole round of matrix instructions to land.
+    const int nround = (ntile + 1) >> 1;
+    if (role == 1) {
+        stage(0, kt_beg);
+        stage(1, kt_beg + 1);
+        for (int q = 0; q < nround; ++q) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // round q has landed
+            barrier_keep_copies();                                // ... for every producer; the consumers are done with round q - 1
+            const int nb = 2 * ((q + 1) & 1);
+            stage(nb, kt_beg + 2 * q + 2);
+            stage(nb + 1, kt_beg + 2 * q + 3);
+        }
+    } else {
+        for (int q = 0; q < nround; ++q) {
+            barrier_keep_copies();
+            const bool two = 2 * q + 1 < ntile;                   // odd tile count: the last round has one tile
+            const unsigned sbase = smem_u + (unsigned)(2 * (q & 1) * STAGE);
+            // A single computing wave per SIMD is bound by instruction issue: the stage base is folded into the twelve
+            // fragment addresses once per round; the vertical tap shift and the second tile of the pair (+ STAGE) are
+            // immediate offsets instead of adds in front of every read.
+            unsigned qb[2][2][3], pbs[2][2];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int hl = 0; hl < 2; ++hl) {
+                    pbs[kk][hl] = sbase + p_addr[kk][hl];
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) qb[kk][hl][d] = sbase + q_addr[kk][hl][d];
+                }
+            // step s of a round = (tile s / 18, half tile (s / 9) & 1, tap s % 9)
+            auto q_frag = [&](int s) -> bf16x8 {
+                const int tl = s / 18, kk = (s / 9) & 1, t = s % 9, dh = t / 3, dw = t % 3;
+                const unsigned lo = qb[kk][0][dw], hi = qb[kk][1][dw];
+                if (tl == 0) {
+                    if (dh == 0) return tr_pair_off<0>(lo, hi);
+                    if (dh == 1) return tr_pair_off<W2 * ROWB>(lo, hi);
+                    return tr_pair_off<2 * W2 * ROWB>(lo, hi);
+                }
+                if (dh == 0) return tr_pair_off<STAGE>(lo, hi);
+                if (dh == 1) return tr_pair_off<STAGE + W2 * ROWB>(lo, hi);
+                return tr_pair_off<STAGE + 2 * W2 * ROWB>(lo, hi);
+            };
+            bf16x8 pb[2][4];
+            auto load_pb = [&](int half, int j0) {   // half = 2 * tile + kk, fragments j0, j0 + 1 into pb[half & 1]
+                const int kk = half & 1;
+#pragma unroll
+                for (int j = j0; j < j0 + 2; ++j) {
+                    unsigned alo = pbs[kk][0], ahi = pbs[kk][1];
+                    if (j) {
+                        asm volatile("v_xor_b32 %0, %1, %2" : "=v"(alo) : "n"(j << 5), "v"(pbs[kk][0]));
+                        asm volatile("v_xor_b32 %0, %1, %2" : "=v"(ahi) : "n"(j << 5), "v"(pbs[kk][1]));
+                    }
+                    pb[kk][j] = half < 2 ? tr_pair_off<0>(alo, ahi) : tr_pair_off<STAGE>(alo, ahi);
+                }
+            };
+            bf16x8 qa[QD + 1];
+            load_pb(0, 0);
+            load_pb(0, 2);
+#pragma unroll
+            for (int d = 0; d < QD; ++d) qa[d] = q_frag(d);
+            // The dY fragments of the next half tile go out in two batches of four reads, at taps TA and TB of the current
+            // half, each right after that step's input fragment.  LDS reads complete in order: the fragment of step s
+            // is ready once no more reads are in flight than were issued after it -- two per later input fragment and
+            // four per batch issued in steps s - QD .. s (a count above the counter's 15 is clamped: a stricter wait).
+            // A batch issued at tap T is complete at the wait of tap T + QD + 1 <= 8, before the next half starts.
+            constexpr int TA = 1, TB = 3;
+            static_assert(TB + QD + 1 <= 8, "dY fragments must land before their half tile starts");
+#pragma unroll
+            for (int st = 0; st < 36; ++st) {
+                const int half = st / 9, t = st % 9;
+                // (requests that run into a second tile that does not exist read stale LDS and are never used)
+                if (st + QD < 36) qa[(st + QD) % (QD + 1)] = q_frag(st + QD);
+                if (half < 3 && t == TA) load_pb(half + 1, 0);
+                if (half < 3 && t == TB) load_pb(half + 1, 2);
+                const int later = 35 - st < QD ? 35 - st : QD;
+                int newer = 2 * later;
+                if (half < 3 && t >= TA && t <= TA + QD) newer += 4;
+                if (half < 3 && t >= TB && t <= TB + QD) newer += 4;
+                frag_wait_n(newer > 15 ? 15 : newer, qa[st % (QD + 1)]);
+                if (st < 18 || two) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[st % (QD + 1)], pb[half & 1][j], acc[t][j], 0, 0, 0);
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // the computing waves hand taps 5-8 to the copying waves through LDS (the stages are dead): eight waves store
+    float4* xch = (float4*)smem + (wave * 64 + lane);
+    if (role == 0) {
+#pragma unroll
+        for (int t = 5; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                xch[((t - 5) * 4 + j) * 256] = make_float4(acc[t][j][0], acc[t][j][1], acc[t][j][2], acc[t][j][3]);
+    }
+    __syncthreads();
+    // acc[t][j][r]: ci = n0 + wave*16 + (lane>>4)*4 + r ; co = m0 + j*16 + (lane&15)
+    float* out = p.slab + (long)split * p.slab_stride;
+    const int ci = n0 + wave * 16 + (lane >> 4) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int co = m0 + j * 16 + (lane & 15);
+        if (role == 0) {
+#pragma unroll
+            for (int t = 0; t < 5; ++t)
+                *(float4*)(out + ((long)co * 9 + t) * p.Ci + ci) = make_float4(acc[t][j][0], acc[t][j][1], acc[t][j][2], acc[t][j][3]);
+        } else {
+#pragma unroll
+            for (int t = 5; t < 9; ++t) *(float4*)(out + ((long)co * 9 + t) * p.Ci + ci) = xch[((t - 5) * 4 + j) * 256];
+        }
+    }
+}
+
+// Which form runs (tuning key "wgrad_pc"): 0 by the K tiles per workgroup, 1 always the producer / consumer form, 2 never.
+// Measured at batch 512, 32x32 (32 K tiles per workgroup): the kernels alone 10-12 % faster (47 -> 41.5, 45 -> 39.5 us),
+// 0.258 -> 0.237 ms per step between events, but the step itself 7 us SLOWER (1.582 -> 1.589 ms, repeatedly, same box);
+// at batch 1024, 64x64 (128 K tiles per workgroup) 1.348 -> 1.23 ms and the step 8.49 -> 8.41 ms.  Hence the threshold.
+int g_wgrad_pc_mode = 0;
+static bool wgrad_use_pc(int kps) { return g_wgrad_pc_mode == 1 || (g_wgrad_pc_mode == 0 && kps >= 64); }
+
 static int ilog2x(int v) {
     if (v <= 0 || (v & (v - 1))) return -1;
     int s = 0;
@@ -370,13 +619,17 @@ extern "C" int vae_conv3_wgrad_patch(const void* dy, const void* x, float* slab,
     const double flops = 2.0 * Cout * Cin * 9.0 * p.Ktot;
     const double bytes = 2.0 * p.Ktot * ((double)Cout + Cin) + 4.0 * nsplit * 9.0 * Cout * Cin;
     ProfScope prof("conv3_wgrad_patch_kernel", flops, bytes, s);
+#define GO(WW)                                                                                          \
+    if (wgrad_use_pc(p.kps)) hipLaunchKernelGGL(conv3_wgrad_pc_kernel<WW>, grid, dim3(512), 0, s, p);      \
+    else hipLaunchKernelGGL(conv3_wgrad_patch_kernel<WW>, grid, dim3(512), 0, s, p)
     switch (W) {
-        case 4: hipLaunchKernelGGL(conv3_wgrad_patch_kernel<4>, grid, dim3(512), 0, s, p); break;
-        case 8: hipLaunchKernelGGL(conv3_wgrad_patch_kernel<8>, grid, dim3(512), 0, s, p); break;
-        case 16: hipLaunchKernelGGL(conv3_wgrad_patch_kernel<16>, grid, dim3(512), 0, s, p); break;
-        case 32: hipLaunchKernelGGL(conv3_wgrad_patch_kernel<32>, grid, dim3(512), 0, s, p); break;
-        default: hipLaunchKernelGGL(conv3_wgrad_patch_kernel<64>, grid, dim3(512), 0, s, p); break;
+        case 4: GO(4); break;
+        case 8: GO(8); break;
+        case 16: GO(16); break;
+        case 32: GO(32); break;
+        default: GO(64); break;
     }
+#undef GO
     VAE_LAUNCH_CHECK("conv3_wgrad_patch_kernel");
     return 0;
 }
