@@ -326,17 +326,16 @@ __global__ __launch_bounds__(512, 1) void conv3_wgrad_patch_kernel(const PatchP 
 // runs its share of the matrix instructions, one after the other: a CU takes in only ~70 GB/s through global->LDS
 // copies, a 1 KB copy holds the issuing wave for ~100-200 cycles, and with two waves per SIMD doing the same work the
 // copy issue (0.9 us per round), the fragment reads and the MFMAs (0.55 us) simply add up.  Here waves 4-7 only copy
-// (a ring of four single-tile stages, three tiles ahead, counted wait) and waves 0-3 only compute, one 64-pixel K tile
-// per barrier: ONE accumulator set per workgroup (no hand-over between groups), and the copies of tile r + 3 run under
-// the matrix instructions of tile r.
+// and waves 0-3 only compute, two 64-pixel K tiles per barrier out of two pairs of stages: ONE accumulator set per
+// workgroup (no hand-over between groups), and the copies of round q + 1 run under the matrix instructions of round q.
 template <int W>
 __global__ __launch_bounds__(512, 1) void conv3_wgrad_pc_kernel(const PatchP p) {
     constexpr int W2 = W + 2;
     constexpr int QD = 2;     // input fragments requested ahead (4 measured: 10 % slower)
     constexpr int P_BYTES = 64 * ROWB, Q_BYTES = PATCH_ROWS_MAX * ROWB, STAGE = P_BYTES + Q_BYTES;
-    constexpr int DUMMY = 4 * STAGE, SMEM_BYTES = DUMMY + 1024;
+    constexpr int SMEM_BYTES = 4 * STAGE;
     constexpr int QI = PATCH_INSTR_PER_WAVE;
-    static_assert(SMEM_BYTES <= 160 * 1024 && 4 * 64 * 16 * 16 <= DUMMY, "LDS");
+    static_assert(SMEM_BYTES <= 160 * 1024 && 4 * 64 * 16 * 16 <= SMEM_BYTES, "LDS");
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -347,7 +346,6 @@ __global__ __launch_bounds__(512, 1) void conv3_wgrad_pc_kernel(const PatchP p) 
 
     int q_st[QI];
     const int ninstr = (p.PR + 7) >> 3;
-    const int nq = max((ninstr + 3) >> 2, 4);       // patch copies per producer wave and tile, the same for all four
 #pragma unroll
     for (int i = 0; i < QI; ++i) {
         const int prow = (wave + 4 * i) * 8 + (lane >> 3);
@@ -365,8 +363,7 @@ __global__ __launch_bounds__(512, 1) void conv3_wgrad_pc_kernel(const PatchP p) 
         __builtin_amdgcn_make_buffer_rsrc((void*)p.P, 0, (int)((unsigned)p.Ktot * (unsigned)p.Co * 2u), 0x00020000);
     const __amdgpu_buffer_rsrc_t q_rsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)p.Q, 0, (int)((unsigned)p.Ktot * (unsigned)p.Ci * 2u), 0x00020000);
-    // exactly 2 + nq copies per producer wave and call (the counted wait depends on it): pieces past the patch and
-    // tiles past the range are zero fills (into the dummy kilobyte / the stage)
+    // a tile past the range is all zero fill
     auto stage = [&](int buf, int kt) {
         unsigned char* pbase = smem + buf * STAGE;
         unsigned char* qbase = pbase + P_BYTES;
@@ -386,25 +383,16 @@ __global__ __launch_bounds__(512, 1) void conv3_wgrad_pc_kernel(const PatchP p) 
         const int h0 = p.G == 1 ? ((k0 >> p.wshift) & (p.H - 1)) : 0;
 #pragma unroll
         for (int i = 0; i < QI; ++i) {
-            if (i < nq) {     // uniform over the workgroup
-                const bool real = wave + 4 * i < ninstr;      // wave-uniform
+            if (wave + 4 * i < ninstr) {     // wave-uniform
                 int st = q_st[i];
                 asm volatile("" : "+v"(st));
                 const int k = k0 + (st & 255) - 128, r = ((st >> 8) & 255) - 1;
                 unsigned off = OOB;
-                if (real && (st >> 24) && (unsigned)(h0 + r) < (unsigned)p.H && (unsigned)k < (unsigned)ktot)
+                if ((st >> 24) && (unsigned)(h0 + r) < (unsigned)p.H && (unsigned)k < (unsigned)ktot)
                     off = (unsigned)k * rowb + (unsigned)(n0 * 2 + ((st >> 12) & 0x70));
-                unsigned char* dst = real ? qbase + (wave + 4 * i) * 1024 : smem + DUMMY;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(q_rsrc, (lptr_t)dst, 16, (int)off, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(q_rsrc, (lptr_t)(qbase + (wave + 4 * i) * 1024), 16, (int)off, 0, 0, 0);
             }
         }
-    };
-    // at most the two youngest tiles' copies of this wave still in flight
-    auto wait_two_tiles = [&]() {
-        if (nq == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else if (nq == 5) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-        else if (nq == 6) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
     };
 
     f32x4 acc[9][4];
