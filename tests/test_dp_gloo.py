@@ -84,6 +84,23 @@ def _worker(rank, port, outdir):
         for s in range(3):              # backward order: decoder+heads, conv4+conv3, conv2+conv1
             red.stage_done(s)
         red.wait()
+        # ---- 3. state replication helpers on a stand-in for the module's flat buffers
+        class Stub:
+            def __init__(self):
+                self.flat_params = torch.full((10,), float(rank + 1))
+                self._bn_stats = torch.arange(6, dtype=torch.float32) * (rank + 1)
+                self._nbt = torch.tensor([3 + rank])
+                self.repacked = 0
+
+            def repack_weights(self):
+                self.repacked += 1
+        m = Stub()
+        dp.broadcast_state(m)
+        assert torch.equal(m.flat_params, torch.full((10,), 1.0)) and int(m._nbt) == 3 and m.repacked == 1
+        assert torch.equal(m._bn_stats, torch.arange(6, dtype=torch.float32))
+        m._bn_stats = torch.arange(6, dtype=torch.float32) * (rank + 1)      # running statistics drift apart per rank
+        dp.sync_bn_stats(m)
+        assert torch.equal(m._bn_stats, torch.arange(6, dtype=torch.float32) * 1.5)
         torch.save({"flat": flat, "loss": loss.detach()}, os.path.join(outdir, f"r{rank}.pt"))
     finally:
         dist.destroy_process_group()
