@@ -39,10 +39,10 @@ def check_bf16(got, ref, what):
     assert rel_l2(got, ref) <= 3e-3, what
 
 
-@pytest.mark.parametrize("n,H,W,Ci", [(2, 8, 8, 3), (3, 32, 32, 3), (1, 4, 8, 1), (96, 32, 32, 3), (300, 16, 16, 3)])
-def test_first_conv_streaming_equals_torch_and_the_tiled_kernel(L, n, H, W, Ci):
+@pytest.mark.parametrize("n,H,W,Ci,Co", [(2, 8, 8, 3, 64), (3, 32, 32, 3, 64), (1, 4, 8, 1, 64), (96, 32, 32, 3, 64),
+                                         (300, 16, 16, 3, 64), (5, 16, 16, 3, 128), (2, 8, 16, 8, 192)])
+def test_first_conv_streaming_equals_torch_and_the_tiled_kernel(L, n, H, W, Ci, Co):
     g = torch.Generator().manual_seed(n + H)
-    Co = 64
     x = bf(torch.rand(n, Ci, H, W, generator=g))
     w = bf(torch.randn(Co, Ci, 3, 3, generator=g) / 5)
     b = torch.randn(Co, generator=g)
