@@ -367,7 +367,17 @@ typedef struct vae_model_cfg {
     void* side_stream;       /* optional second hipStream_t: vae_model_backward runs the weight-gradient
                               * kernels there, beside the dgrad / BatchNorm chain on `stream`, and
                               * re-joins `stream` before it returns.  NULL: everything on `stream`. */
+    int precision;           /* 0 (VAE_PRECISION_BF16): bf16 MFMA operands and bf16 activations, fp32 accumulation -- the
+                              * throughput path.  1 (VAE_PRECISION_FP32): the reference's own arithmetic type
+                              * (vae/training/train.py:430-431 trains in fp32): NCHW fp32 tensors, parameters read in
+                              * their own layouts (wpack is not used and may be NULL), sums of products accumulated in
+                              * fp64 and rounded to fp32 once.  Same entry points, same params / grads / bn_stats
+                              * buffers; vae_model_workspace_bytes depends on it.  In this mode vae_model_backward
+                              * writes all 52 gradients (the biases in front of a BatchNorm get their rounding-noise
+                              * sums, as in the reference) and ignores side_stream. */
 } vae_model_cfg;
+#define VAE_PRECISION_BF16 0
+#define VAE_PRECISION_FP32 1
 
 long vae_model_param_count(const vae_model_cfg* cfg);              /* floats in params / grads */
 long vae_model_param_offset(const vae_model_cfg* cfg, int index);  /* index 0..51 */

@@ -103,6 +103,26 @@ def test_workspace_is_deterministic_and_grows_with_batch():
     assert L.call("vae_model_wpack_bytes", ctypes.byref(_cfg(64, 128, 32))) > 2 * 4086787 * 0.9
 
 
+def test_precision_field_selects_the_workspace_layout_and_is_checked():
+    """vae_model_cfg.precision: 0 = bf16 kernels, 1 = fp32 kernels (own workspace layout, no packed weights);
+    anything else is rejected.  The ctypes mirror must match the C struct field for field."""
+    lib = L.load()
+    bf = _cfg(64, 128, 32)
+    assert bf.precision == L.PRECISIONS["bf16"] == 0
+    fp = _cfg(64, 128, 32)
+    fp.precision = L.PRECISIONS["fp32"]
+    a, b = L.call("vae_model_workspace_bytes", ctypes.byref(bf)), L.call("vae_model_workspace_bytes", ctypes.byref(fp))
+    assert a > 0 and b > 0 and a != b
+    # fp32 activations: at least 4 bytes for every element of the eleven saved pre-BatchNorm tensors
+    assert b > 64 * 4 * (2 * 64 * 1024 + 2 * 128 * 256 + 2 * 256 * 64 + 2 * 256 * 16)
+    # parameter layout does not depend on the precision
+    assert L.call("vae_model_param_count", ctypes.byref(bf)) == L.call("vae_model_param_count", ctypes.byref(fp))
+    bad = _cfg(64, 128, 32)
+    bad.precision = 7
+    assert lib.vae_model_workspace_bytes(ctypes.byref(bad)) < 0
+    assert b"precision" in lib.vae_last_error()
+
+
 def test_bad_model_config_is_an_error_not_a_crash():
     lib = L.load()
     bad = _cfg(8, 128, 20)          # three 2x2 pools need a multiple of 8

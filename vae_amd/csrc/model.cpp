@@ -13,96 +13,10 @@
 
 #include "../../include/vae_hip.h"
 
-namespace vae {
-void set_error(const char* fmt, ...);
-}
-
-#define CHECK(cond, ...)                   \
-    do {                                   \
-        if (!(cond)) {                     \
-            ::vae::set_error(__VA_ARGS__); \
-            return 1;                      \
-        }                                  \
-    } while (0)
-#define TRY(expr)                 \
-    do {                          \
-        int e__ = (expr);         \
-        if (e__) return e__;      \
-    } while (0)
+#include "model_layout.h"
 
 namespace {
-
-const int ENC_C[4] = {64, 128, 256, 256};
-const int DEC_CI[3] = {256, 128, 64};   // up3, up2, up1
-const int DEC_CO[3] = {128, 64, 64};
-
-inline long align_up(long v, long a) { return (v + a - 1) / a * a; }
-
-// ------------------------------------------------------------------ parameter layout
-enum {
-    P_FC_MU_W = 32, P_FC_MU_B, P_FC_LV_W, P_FC_LV_B, P_FC_UP_W, P_FC_UP_B,
-    P_UP3_W, P_UP3_B, P_BN3_G, P_BN3_B, P_UP2_W, P_UP2_B, P_BN2_G, P_BN2_B,
-    P_UP1_W, P_UP1_B, P_BN1_G, P_BN1_B, P_HEAD_W, P_HEAD_B, P_COUNT
-};
-// encoder block b (0..3): conv a weight = 8b, bias 8b+1, gamma 8b+2, beta 8b+3, conv b weight 8b+4, ...
-
-struct Dims {
-    int N, Cin, Cout, L, S, hw, F;   // hw = (S/8)^2, F = 256*hw
-};
-
-struct ParamLayout {
-    long off[P_COUNT], numel[P_COUNT], total;
-    long bn_off[11], bn_total;   // running_mean at bn_off, running_var at bn_off + C
-    int bn_c[11];
-};
-
-int make_dims(const vae_model_cfg* c, Dims* d, const char* who) {
-    CHECK(c, "%s: null config", who);
-    CHECK(c->batch > 0, "%s: batch must be > 0 (got %d)", who, c->batch);
-    CHECK(c->in_channels >= 1 && c->in_channels <= 8, "%s: in_channels=%d not supported (1..8)", who, c->in_channels);
-    CHECK(c->out_channels >= 1 && c->out_channels <= 4, "%s: out_channels=%d not supported (1..4)", who, c->out_channels);
-    CHECK(c->image_size >= 8 && c->image_size % 8 == 0, "%s: image_size=%d must be a positive multiple of 8", who, c->image_size);
-    CHECK(c->latent >= 64 && c->latent % 64 == 0, "%s: latent_dims=%d must be a positive multiple of 64", who, c->latent);
-    CHECK(c->p_dropout >= 0.0 && c->p_dropout < 1.0, "%s: p_dropout=%f out of [0,1)", who, c->p_dropout);
-    CHECK((long)c->batch * c->image_size * c->image_size < (1L << 31), "%s: batch x image_size^2 exceeds 2^31 pixels", who);
-    d->N = c->batch; d->Cin = c->in_channels; d->Cout = c->out_channels; d->L = c->latent; d->S = c->image_size;
-    d->hw = (d->S / 8) * (d->S / 8);
-    d->F = 256 * d->hw;
-    return 0;
-}
-
-void make_param_layout(const Dims& d, ParamLayout* pl) {
-    long o = 0;
-    auto put = [&](int idx, long n) {
-        pl->off[idx] = o;
-        pl->numel[idx] = n;
-        o += align_up(n, 4);
-    };
-    int ci = d.Cin;
-    for (int b = 0; b < 4; ++b) {
-        const int co = ENC_C[b];
-        put(8 * b + 0, (long)co * ci * 9); put(8 * b + 1, co); put(8 * b + 2, co); put(8 * b + 3, co);
-        put(8 * b + 4, (long)co * co * 9); put(8 * b + 5, co); put(8 * b + 6, co); put(8 * b + 7, co);
-        ci = co;
-    }
-    put(P_FC_MU_W, (long)d.L * d.F); put(P_FC_MU_B, d.L);
-    put(P_FC_LV_W, (long)d.L * d.F); put(P_FC_LV_B, d.L);
-    put(P_FC_UP_W, (long)d.F * d.L); put(P_FC_UP_B, d.F);
-    for (int u = 0; u < 3; ++u) {
-        const int base = P_UP3_W + 4 * u;
-        put(base, (long)DEC_CI[u] * DEC_CO[u] * 4); put(base + 1, DEC_CO[u]); put(base + 2, DEC_CO[u]); put(base + 3, DEC_CO[u]);
-    }
-    put(P_HEAD_W, (long)d.Cout * 64); put(P_HEAD_B, d.Cout);
-    pl->total = o;
-    long bo = 0;
-    for (int i = 0; i < 11; ++i) {
-        const int C = i < 8 ? ENC_C[i / 2] : DEC_CO[i - 8];
-        pl->bn_c[i] = C;
-        pl->bn_off[i] = bo;
-        bo += 2 * C;
-    }
-    pl->bn_total = bo;
-}
+using namespace vae_model;
 
 // ------------------------------------------------------------------ packed-weight layout (bf16 unless noted)
 struct PackLayout {
@@ -315,6 +229,7 @@ extern "C" long vae_model_wpack_bytes(const vae_model_cfg* cfg) {
 extern "C" long vae_model_workspace_bytes(const vae_model_cfg* cfg) {
     Ctx c;
     if (make_ctx(&c, cfg, "vae_model_workspace_bytes")) return -1;
+    if (cfg->precision == VAE_PRECISION_FP32) return f32_workspace_bytes(c.d);
     return c.ws.total_bytes;
 }
 
@@ -418,6 +333,10 @@ extern "C" int vae_model_forward(const vae_model_cfg* cfg, const float* params, 
                                  float* recon, float* mu, float* logvar, void* stream) {
     Ctx c;
     TRY(make_ctx(&c, cfg, "vae_model_forward"));
+    if (cfg->precision == VAE_PRECISION_FP32) {
+        CHECK(params && bn_stats && workspace && x && recon && mu && logvar, "vae_model_forward: null pointer");
+        return f32_forward(cfg, c.d, c.pl, params, bn_stats, workspace, x, eps_in, keep_masks, nullptr, recon, mu, logvar, 3, stream);
+    }
     CHECK(params && bn_stats && wpack && workspace && x && recon && mu && logvar, "vae_model_forward: null pointer");
     c.params = (float*)params; c.bn = bn_stats; c.wpack = (char*)wpack; c.w = (char*)workspace; c.stream = stream;
     TRY(encoder_forward(c, x, keep_masks, mu, logvar));
@@ -431,6 +350,10 @@ extern "C" int vae_model_encode(const vae_model_cfg* cfg, const float* params, f
                                 float* logvar, void* stream) {
     Ctx c;
     TRY(make_ctx(&c, cfg, "vae_model_encode"));
+    if (cfg->precision == VAE_PRECISION_FP32) {
+        CHECK(params && bn_stats && workspace && x && mu && logvar, "vae_model_encode: null pointer");
+        return f32_forward(cfg, c.d, c.pl, params, bn_stats, workspace, x, nullptr, keep_masks, nullptr, nullptr, mu, logvar, 1, stream);
+    }
     CHECK(params && bn_stats && wpack && workspace && x && mu && logvar, "vae_model_encode: null pointer");
     c.params = (float*)params; c.bn = bn_stats; c.wpack = (char*)wpack; c.w = (char*)workspace; c.stream = stream;
     return encoder_forward(c, x, keep_masks, mu, logvar);
@@ -440,6 +363,10 @@ extern "C" int vae_model_decode(const vae_model_cfg* cfg, const float* params, f
                                 void* workspace, const float* z, float* recon, void* stream) {
     Ctx c;
     TRY(make_ctx(&c, cfg, "vae_model_decode"));
+    if (cfg->precision == VAE_PRECISION_FP32) {
+        CHECK(params && bn_stats && workspace && z && recon, "vae_model_decode: null pointer");
+        return f32_forward(cfg, c.d, c.pl, params, bn_stats, workspace, nullptr, nullptr, nullptr, z, recon, nullptr, nullptr, 2, stream);
+    }
     CHECK(params && bn_stats && wpack && workspace && z && recon, "vae_model_decode: null pointer");
     c.params = (float*)params; c.bn = bn_stats; c.wpack = (char*)wpack; c.w = (char*)workspace; c.stream = stream;
     TRY(vae_cast_bf16(z, c.at(c.ws.zb), (long)c.d.N * c.d.L, stream));
@@ -450,7 +377,7 @@ extern "C" int vae_model_kl_partials(const vae_model_cfg* cfg, void* workspace, 
     Ctx c;
     TRY(make_ctx(&c, cfg, "vae_model_kl_partials"));
     CHECK(workspace && kl_partial && n, "vae_model_kl_partials: null pointer");
-    *kl_partial = (const float*)((char*)workspace + c.ws.klp);
+    *kl_partial = (const float*)((char*)workspace + (cfg->precision == VAE_PRECISION_FP32 ? f32_klp_offset(c.d) : c.ws.klp));
     *n = vae_reparam_grid((long)c.d.N * c.d.L);
     return 0;
 }
@@ -695,9 +622,13 @@ extern "C" int vae_model_backward(const vae_model_cfg* cfg, const float* params,
                                   const float* dlv_ext, float kl_scale, float* grads, int stage, void* stream) {
     Ctx c;
     TRY(make_ctx(&c, cfg, "vae_model_backward"));
-    CHECK(params && wpack && workspace && d_recon && recon && mu && logvar && grads, "vae_model_backward: null pointer");
+    CHECK(params && (wpack || cfg->precision == VAE_PRECISION_FP32) && workspace && d_recon && recon && mu && logvar && grads,
+          "vae_model_backward: null pointer");
     CHECK(cfg->train, "vae_model_backward: the forward pass must have run in train mode");
     CHECK(stage >= -1 && stage <= 2, "vae_model_backward: stage=%d out of range (-1 all, 0 decoder+latent, 1 conv4+conv3, 2 conv2+conv1)", stage);
+    if (cfg->precision == VAE_PRECISION_FP32)
+        return f32_backward(cfg, c.d, c.pl, params, workspace, d_recon, recon, mu, logvar, eps_in, keep_masks, dmu_ext, dlv_ext,
+                            kl_scale, grads, stage, stream);
     c.params = (float*)params; c.grads = grads; c.wpack = (char*)wpack; c.w = (char*)workspace; c.stream = stream;
     Fork f;
     TRY(fork_init(&f, stream, cfg->side_stream));

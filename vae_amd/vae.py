@@ -15,6 +15,12 @@ names are unchanged.  The kernels read bf16 packed copies of the weights; they a
 before a pass whenever any parameter's (or the flat buffer's) autograd version counter has
 moved since the last pack -- torch optimizers, load_state_dict, p.copy_() and p.add_() all
 bump the counter of the Parameter they write, not the flat buffer's.
+
+Precision: ``model.set_precision("fp32")`` switches the same module (same buffers, same entry
+points) to the library's fp32 kernels -- the reference's own arithmetic type
+(vae/training/train.py:430-431): NCHW fp32 activations, parameters read unpacked, sums in fp64.
+That mode reproduces the reference to fp32 rounding, gradients included; the default "bf16"
+mode is the throughput path (bf16 matrix-core operands, fp32 accumulation).
 """
 from __future__ import annotations
 
@@ -114,6 +120,16 @@ class VAEConv(nn.Module):
         # (measured +0.5 % at batch 512, 32x32: the chain leaves few idle CUs; off by default)
         self.use_side_stream = False
         self._side_stream = None
+        self.precision = "bf16"     # or "fp32": see set_precision
+
+    def set_precision(self, precision: str):
+        """"bf16" (default): bf16 MFMA kernels.  "fp32": the library's fp32 kernels, which match the fp32 reference
+        to rounding (outputs, loss and every gradient).  Parameters, optimizer state and checkpoints are fp32 in
+        both modes, so the mode can change between any two passes."""
+        if precision not in _lib.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}, got {precision!r}")
+        self.precision = precision
+        return self
 
     # ------------------------------------------------------------------ layout helpers
     def _ordered_params(self):
@@ -137,7 +153,7 @@ class VAEConv(nn.Module):
                              latent=hp["latent_dims"], image_size=hp["image_size"], train=int(train),
                              p_dropout=hp["p_dropout"], seed=int(self.rng_seed),
                              step=int(self.rng_step if step is None else step) & 0xFFFFFFFF, rank=int(self.rank),
-                             side_stream=side)
+                             side_stream=side, precision=_lib.PRECISIONS[self.precision])
 
     def _flatten(self, device):
         """Move parameters / running stats into the flat buffers the kernels use (views keep
@@ -207,7 +223,11 @@ class VAEConv(nn.Module):
         return (self.flat_params._version, sum(p._version for p in ps), ps[0].data_ptr(), ps[-1].data_ptr())
 
     def repack_weights(self):
-        """refresh the bf16 operand copies from flat_params (call after a raw-pointer update)."""
+        """refresh the bf16 operand copies from flat_params (call after a raw-pointer update).  The fp32 kernels read
+        the parameters themselves: in that mode the copies are only marked stale."""
+        if self.precision != "bf16":
+            self._packed_version = None
+            return
         cfg = self._cfg(1, True)
         _lib.check_device(self.flat_params)
         _lib.call("vae_model_pack_weights", ctypes.byref(cfg), self.flat_params.data_ptr(), self._wpack.data_ptr(),
@@ -226,19 +246,21 @@ class VAEConv(nn.Module):
         if self._param_list[0].data_ptr() != self.flat_params.data_ptr():
             raise RuntimeError("a parameter no longer lives in the module's flat buffer (its .data was re-assigned, e.g. "
                                "load_state_dict(assign=True)): call model.to(device) again to re-attach the parameters")
-        if self._packed_version != self._weights_signature():
+        if self.precision == "bf16" and self._packed_version != self._weights_signature():
             self.repack_weights()
 
     def _workspace(self, batch):
-        pool = self._ws_pool.setdefault(batch, [])
+        cfg = self._cfg(batch, True)
+        nbytes = _lib.load().vae_model_workspace_bytes(ctypes.byref(cfg))     # depends on batch and precision
+        if nbytes < 0:
+            raise RuntimeError(f"unsupported VAEConv configuration: {_lib.load().vae_last_error().decode()}")
+        pool = self._ws_pool.setdefault(nbytes, [])
         if pool:
             return pool.pop()
-        cfg = self._cfg(batch, True)
-        nbytes = _lib.load().vae_model_workspace_bytes(ctypes.byref(cfg))
         return torch.empty(nbytes, dtype=torch.uint8, device=self.flat_params.device)
 
     def _release_workspace(self, batch, ws):
-        pool = self._ws_pool.setdefault(batch, [])
+        pool = self._ws_pool.setdefault(ws.numel(), [])
         if len(pool) < 2:
             pool.append(ws)
 
