@@ -38,6 +38,7 @@ if ROOT not in sys.path:
 
 PEAK_TFLOPS_BF16 = 2500.0     # dense bf16 MFMA peak of one MI355X
 PEAK_HBM_GBS = 8000.0         # HBM3E peak of one MI355X
+PEAK_TFLOPS_FP32 = 157.3      # fp32 vector / matrix peak of one MI355X (the fp32 mode's kernels)
 
 
 def train_flops_per_image(in_ch, latent, S):
@@ -100,7 +101,8 @@ def profile_pass(step_fn, batches, nsteps=3):
         rec = {"kernel": name, "launches_per_step": launches[k] / nsteps, "ms_per_step": ms[k] / nsteps,
                "avg_us": 1e3 * ms[k] / max(launches[k], 1), "bound": "mfma" if mfma else "hbm"}
         if mfma:
-            rec.update(achieved=fl[k] / t / 1e12 if t > 0 else 0.0, peak=PEAK_TFLOPS_BF16, unit="TFLOP/s")
+            peak = PEAK_TFLOPS_FP32 if name.startswith("gemm_f32") else PEAK_TFLOPS_BF16
+            rec.update(achieved=fl[k] / t / 1e12 if t > 0 else 0.0, peak=peak, unit="TFLOP/s")
         else:
             rec.update(achieved=by[k] / t / 1e9 if t > 0 else 0.0, peak=PEAK_HBM_GBS, unit="GB/s")
         rec["frac"] = rec["achieved"] / rec["peak"]
@@ -215,6 +217,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="cfg2_1gpu")
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch size")
+    ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16",
+                    help="bf16: the matrix-core path (the headline).  fp32: the library's fp32 kernels, the reference's own "
+                         "arithmetic type (e.g. --config cfg1_cpu --precision fp32 = the reference's CPU configuration on the GPU)")
     ap.add_argument("--side-stream", action="store_true",
                     help="run the weight-gradient kernels of the backward pass on a second stream")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=INT",
@@ -282,6 +287,7 @@ def main():
     model = VAEConv(Cin, 3, Lat, float(conf.p_dropout), S).to(dev).train()
     model.rng_seed, model.rank = int(conf.seed), rank
     model.use_side_stream = bool(args.side_stream)
+    model.set_precision(args.precision)
     broadcast_state(model)
     if args.torch_optimizer:
         opt = torch.optim.AdamW(model.parameters(), lr=float(conf.lr))
@@ -335,12 +341,13 @@ def main():
             "n_ranks_seen": n_ranks_seen,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "ms_per_step_median": per_step[len(per_step) // 2], "ms_per_step_min": per_step[0],
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: VAEConv({Cin},3,{Lat},{float(conf.p_dropout)},{S}) full train step "
                                    f"(fwd + {conf.recon_loss}/KL loss + bwd + clip + AdamW), batch {batch} per GPU",
                        "global_batch": world * batch, "parallelism": f"dp{world}"},
             "model_tflops": ips * fpi / 1e12,
-            "model_mfma_frac": ips * fpi / 1e12 / (PEAK_TFLOPS_BF16 * world),
+            "model_mfma_frac": ips * fpi / 1e12 / ((PEAK_TFLOPS_BF16 if args.precision == "bf16" else PEAK_TFLOPS_FP32) * world),
             "final_loss": final_loss,
         }
         if kernels:
