@@ -104,6 +104,41 @@ def test_checkpoint_and_sampling_through_the_model(tmp_path):
     data.save_image_grid(s1, str(tmp_path / "samples.ppm"), nrow=3)
 
 
+def test_interpolate_latents_and_command_line(tmp_path):
+    """interpolate_latents (train.py:115-155): the end points are the decodes of the two images' means and the steps
+    walk the straight line between them; `python -m vae_amd` runs sample / reconstruct / interpolate from a
+    checkpoint the way the reference's load_and_test_model does (train.py:182-229)."""
+    from vae_amd import data
+    from vae_amd.__main__ import main
+    from vae_amd.vae import VAEConv
+    torch.manual_seed(5)
+    m = VAEConv(3, 3, 128, 0.1, 32).to(DEV).eval()
+    x = torch.rand(2, 3, 32, 32, device=DEV)
+    walk = data.interpolate_latents(m, x[0], x[1].unsqueeze(0), num_steps=5)
+    assert walk.shape == (5, 3, 32, 32)
+    with torch.no_grad():
+        mu, _ = m.encode(x)
+        ends = m.decode(mu)
+        mid = m.decode((0.5 * mu[0:1] + 0.5 * mu[1:2]).contiguous())
+    assert torch.allclose(walk[0], ends[0], atol=2e-3) and torch.allclose(walk[4], ends[1], atol=2e-3)
+    assert torch.allclose(walk[2], mid[0], atol=2e-3)
+    with pytest.raises(ValueError):
+        data.interpolate_latents(m, x[0], x[1], num_steps=1)
+    ckpt = str(tmp_path / "best-model.pth")
+    data.save_checkpoint(m, ckpt)
+    imgs = (torch.rand(12, 32, 32, 3) * 255).to(torch.uint8).numpy()
+    np.save(str(tmp_path / "val.npy"), imgs)
+    for cmd, extra, shape_rows in (("sample", ["--n", "6"], 1), ("reconstruct", ["--n", "4", "--images", str(tmp_path / "val.npy")], 2),
+                                   ("interpolate", ["--steps", "7", "--images", str(tmp_path / "val.npy")], 1),
+                                   ("interpolate", ["--steps", "4", "--precision", "fp32"], 1)):
+        out = str(tmp_path / f"{cmd}.ppm")
+        assert main([cmd, "--checkpoint", ckpt, "--config", "cfg2_1gpu", "--out", out] + extra) == 0
+        with open(out, "rb") as f:
+            assert f.read(2) == b"P6"
+    with pytest.raises(SystemExit):
+        main(["reconstruct", "--images", str(tmp_path / "val.npy"), "--n", "50", "--out", str(tmp_path / "x.ppm")])
+
+
 def test_fit_runs_the_reference_epoch_loop(tmp_path):
     """train pass, eval pass, best-model checkpoint on improvement, one record per epoch (train.py:316-373)"""
     from vae_amd.data import DeviceFeed, load_checkpoint, split_indices

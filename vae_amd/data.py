@@ -7,8 +7,9 @@
   worker or PCIe copy runs per step.
 * ``save_checkpoint`` / ``load_checkpoint`` write and read the reference's ``best-model.pth``: a
   plain ``state_dict`` (train.py:360-367, 187-207), loaded with ``weights_only=True``.
-* ``sample`` / ``reconstruct`` / ``save_image_grid`` cover train.py:58-112 (show_reconstructions,
-  show_samples) without matplotlib: they return tensors and write a PPM/PNG grid.
+* ``sample`` / ``reconstruct`` / ``interpolate_latents`` / ``save_image_grid`` cover train.py:58-155
+  (show_reconstructions, show_samples, interpolate_latents) without matplotlib: they return tensors and write a
+  PPM/PNG grid.  ``python -m vae_amd`` runs them from a checkpoint (vae_amd/__main__.py).
 
 There is no CPU path here either: ``DeviceFeed`` calls the HIP library and fails if it is absent.
 """
@@ -134,6 +135,25 @@ def reconstruct(model, inputs: torch.Tensor) -> torch.Tensor:
     recon = model(inputs)[0]
     model.train(was_training)
     return recon
+
+
+@torch.no_grad()
+def interpolate_latents(model, x1: torch.Tensor, x2: torch.Tensor, num_steps: int = 10) -> torch.Tensor:
+    """The reference's latent walk (interpolate_latents, train.py:115-155): encode two images to their means, decode
+    ``(1 - a) * mu1 + a * mu2`` for ``a`` in ``linspace(0, 1, num_steps)``.  ``x1`` / ``x2``: ``[C, S, S]`` or
+    ``[1, C, S, S]`` in [0, 1].  Returns ``[num_steps, C_out, S, S]`` (all steps decoded as ONE batch)."""
+    if num_steps < 2:
+        raise ValueError(f"num_steps={num_steps}: need at least the two end points")
+    was_training = model.training
+    model.eval()
+    dev = next(model.parameters()).device
+    pair = torch.stack([x1.reshape(x1.shape[-3:]), x2.reshape(x2.shape[-3:])]).to(device=dev, dtype=torch.float32)
+    mu, _ = model.encode(pair)
+    alpha = torch.linspace(0, 1, steps=num_steps, device=dev).unsqueeze(1)
+    z = (1 - alpha) * mu[0:1] + alpha * mu[1:2]
+    out = model.decode(z.contiguous())
+    model.train(was_training)
+    return out
 
 
 def save_image_grid(images: torch.Tensor, path: str, nrow: int = 8, padding: int = 2) -> None:
