@@ -419,7 +419,9 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
                                                        float* __restrict__ partial, bf16_t* __restrict__ dy, long npix,
                                                        int hw, int hwshift) {
     constexpr int ROWS = 3 + CO;
-    __shared__ float red[ROWS][32][64 + 1];
+    // per-wave partial sums only (the eight pixel lanes of a wave are folded by shuffles first): 6 KB instead of the
+    // 50 KB a [row][pixel lane][channel] array takes, which held a CU to three workgroups
+    __shared__ float red[ROWS][4][64];
     const int sub = threadIdx.x & 7, c0 = sub * 8, pl = threadIdx.x >> 3;
     float sc[8], sh[8], mu[8], rs[8], wv[CO][8], c1[8], c2[8];
     load8f(scale + c0, sc);
@@ -502,23 +504,42 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
         }
     }
     if (PASS == 0) {
+        // lanes l, l ^ 8, l ^ 16, l ^ 32 hold the same channels of different pixels
+        auto fold8 = [](float v) {
+            v += __shfl_xor(v, 8, 64);
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            return v;
+        };
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            red[0][pl][c0 + i] = a_gx[i];
-            red[1][pl][c0 + i] = a_g[i];
+            a_gx[i] = fold8(a_gx[i]);
+            a_g[i] = fold8(a_g[i]);
 #pragma unroll
-            for (int o = 0; o < CO; ++o) red[2 + o][pl][c0 + i] = a_w[o][i];
+            for (int o = 0; o < CO; ++o) a_w[o][i] = fold8(a_w[o][i]);
         }
-        if (sub == 0) {
 #pragma unroll
-            for (int o = 0; o < CO; ++o) red[2 + CO][pl][o] = a_b[o];
+        for (int o = 0; o < CO; ++o) a_b[o] = fold8(a_b[o]);
+        const int wv_i = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) < 8) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                red[0][wv_i][c0 + i] = a_gx[i];
+                red[1][wv_i][c0 + i] = a_g[i];
+#pragma unroll
+                for (int o = 0; o < CO; ++o) red[2 + o][wv_i][c0 + i] = a_w[o][i];
+            }
+            if (sub == 0) {
+#pragma unroll
+                for (int o = 0; o < CO; ++o) red[2 + CO][wv_i][o] = a_b[o];
+            }
         }
         __syncthreads();
         for (int j = threadIdx.x; j < ROWS * 64; j += blockDim.x) {
             const int row = j >> 6, c = j & 63;
             float s = 0.f;
             if (row < 2 + CO || c < CO)
-                for (int t = 0; t < 32; ++t) s += red[row][t][c];
+                for (int t = 0; t < 4; ++t) s += red[row][t][c];
             partial[(long)blockIdx.x * ROWS * 64 + j] = s;
         }
     }
@@ -705,9 +726,11 @@ extern "C" int vae_head_fwd(const void* y, const float* scale, const float* shif
 }
 
 extern "C" int vae_head_bwd_blocks(int n_img, int H, int W) {
+    // pass 0 keeps 43 running sums per lane (164 VGPRs): three workgroups share a CU, so 768 is one full round of
+    // resident workgroups on 256 CUs (1024 left a second round of 256 that ran alone)
     long b = ((long)n_img * H * W + 31) / 32;
     if (b < 1) b = 1;
-    if (b > 1024) b = 1024;
+    if (b > 768) b = 768;
     return (int)b;
 }
 
