@@ -44,27 +44,38 @@ __device__ __forceinline__ float at4(const float* t, int n, int C, int c, int H,
     if ((unsigned)h >= (unsigned)H || (unsigned)w >= (unsigned)W) return 0.f;
     return t[(((long)n * C + c) * H + h) * W + w];
 }
+// k -> (channel, kernel row, kernel column) of a KS x KS kernel; KS is a compile-time constant, so the divisions
+// are multiplications
+template <int KS>
+__device__ __forceinline__ void tap_of(int k, int& c, int& kh, int& kw) {
+    constexpr int KS2 = KS * KS;
+    c = k / KS2;
+    const int t = k - c * KS2;
+    kh = t / KS;
+    kw = t - kh * KS;
+}
 
-template <int MODE>
-__device__ __forceinline__ float load_a(const G32& g, int m, int k) {
+// An operand tile is fetched element by element through these maps.  The index that is a PIXEL (m of the forward /
+// input-gradient modes, k of the weight-gradient modes) is decomposed into (image, row, column) by the caller, once per
+// thread and tile row where it is the tile's row index: `pm` is that decomposition when the mode's m is a pixel.
+template <int MODE, int KS>
+__device__ __forceinline__ float load_a(const G32& g, int m, int k, const Pix& pm) {
     if constexpr (MODE == CONV_FWD) {
-        const Pix p = pix_of(g, m);
-        const int ks2 = g.ks * g.ks, ci = k / ks2, t = k - ci * ks2, kh = t / g.ks, kw = t - kh * g.ks;
-        return at4(g.a, p.n, g.Ci, ci, g.H, g.W, p.h + kh - g.pad, p.w + kw - g.pad);
+        int ci, kh, kw;
+        tap_of<KS>(k, ci, kh, kw);
+        return at4(g.a, pm.n, g.Ci, ci, g.H, g.W, pm.h + kh - g.pad, pm.w + kw - g.pad);
     } else if constexpr (MODE == CONV_DGRAD) {
-        const Pix p = pix_of(g, m);
-        const int ks2 = g.ks * g.ks, co = k / ks2, t = k - co * ks2, kh = t / g.ks, kw = t - kh * g.ks;
-        return at4(g.a, p.n, g.Co, co, g.H, g.W, p.h + g.pad - kh, p.w + g.pad - kw);
+        int co, kh, kw;
+        tap_of<KS>(k, co, kh, kw);
+        return at4(g.a, pm.n, g.Co, co, g.H, g.W, pm.h + g.pad - kh, pm.w + g.pad - kw);
     } else if constexpr (MODE == CONV_WGRAD) {
         const Pix p = pix_of(g, k);
         return g.a[(((long)p.n * g.Co + m) * g.H + p.h) * g.W + p.w];
     } else if constexpr (MODE == CONVT_FWD) {
-        const Pix p = pix_of(g, m);
-        return g.a[(((long)p.n * g.Ci + k) * g.H + p.h) * g.W + p.w];
+        return g.a[(((long)pm.n * g.Ci + k) * g.H + pm.h) * g.W + pm.w];
     } else if constexpr (MODE == CONVT_DGRAD) {
-        const Pix p = pix_of(g, m);
         const int co = k >> 2, kh = (k >> 1) & 1, kw = k & 1;
-        return g.a[(((long)p.n * g.Co + co) * (2 * g.H) + 2 * p.h + kh) * (2 * g.W) + 2 * p.w + kw];
+        return g.a[(((long)pm.n * g.Co + co) * (2 * g.H) + 2 * pm.h + kh) * (2 * g.W) + 2 * pm.w + kw];
     } else if constexpr (MODE == CONVT_WGRAD) {
         const Pix p = pix_of(g, k);
         return g.a[(((long)p.n * g.Ci + m) * g.H + p.h) * g.W + p.w];
@@ -75,16 +86,18 @@ __device__ __forceinline__ float load_a(const G32& g, int m, int k) {
     }
 }
 
-template <int MODE>
+template <int MODE, int KS>
 __device__ __forceinline__ float load_b(const G32& g, int k, int n) {
     if constexpr (MODE == CONV_FWD) {
         return g.b[(long)n * g.K + k];
     } else if constexpr (MODE == CONV_DGRAD) {
-        const int ks2 = g.ks * g.ks, co = k / ks2, t = k - co * ks2;
-        return g.b[((long)co * g.Ci + n) * ks2 + t];
+        constexpr int KS2 = KS * KS;
+        const int co = k / KS2, t = k - co * KS2;
+        return g.b[((long)co * g.Ci + n) * KS2 + t];
     } else if constexpr (MODE == CONV_WGRAD) {
         const Pix p = pix_of(g, k);
-        const int ks2 = g.ks * g.ks, ci = n / ks2, t = n - ci * ks2, kh = t / g.ks, kw = t - kh * g.ks;
+        int ci, kh, kw;
+        tap_of<KS>(n, ci, kh, kw);
         return at4(g.b, p.n, g.Ci, ci, g.H, g.W, p.h + kh - g.pad, p.w + kw - g.pad);
     } else if constexpr (MODE == CONVT_FWD) {
         return g.b[(long)k * g.N + n];
@@ -135,29 +148,45 @@ __device__ __forceinline__ void store_c(const G32& g, int m, int n, double acc, 
 
 constexpr int TM = 64, TN = 64, TK = 16, LDT = 68;     // tile; LDS row stride (floats)
 
-template <int MODE>
+template <int MODE> struct MIsPixel { static constexpr bool value = MODE == CONV_FWD || MODE == CONV_DGRAD || MODE == CONVT_FWD || MODE == CONVT_DGRAD; };
+
+template <int MODE, int KS>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const G32 g) {
+    // (tiles staged as fp64 -- one conversion per operand instead of one per product -- measured slower: 7.6 vs 10.3
+    // TFLOP/s, the doubled LDS reads cost more than the conversions)
     __shared__ __attribute__((aligned(16))) float As[TK][LDT];
     __shared__ __attribute__((aligned(16))) float Bs[TK][LDT];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN, z = blockIdx.z;
     const int kbeg = z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+    // the tile rows / columns this thread fetches are the same in every K step: (mm[i], kk[i]) of A, (nn[i], kb[i]) of B
+    int mm[4], ka[4], nn[4], kb[4];
+    Pix pm[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (Traits<MODE>::a_kfast) { ka[i] = tid & 15; mm[i] = (tid >> 4) + 16 * i; }
+        else { mm[i] = tid & 63; ka[i] = (tid >> 6) + 4 * i; }
+        if (Traits<MODE>::b_kfast) { kb[i] = tid & 15; nn[i] = (tid >> 4) + 16 * i; }
+        else { nn[i] = tid & 63; kb[i] = (tid >> 6) + 4 * i; }
+        pm[i] = Pix{0, 0, 0};
+        if (MIsPixel<MODE>::value && m0 + mm[i] < g.M) pm[i] = pix_of(g, m0 + mm[i]);
+    }
     double acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
     for (int k0 = kbeg; k0 < kend; k0 += TK) {
+        float av[4], bv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {       // all eight loads of a step are requested before any is stored
+            av[i] = (m0 + mm[i] < g.M && k0 + ka[i] < kend) ? load_a<MODE, KS>(g, m0 + mm[i], k0 + ka[i], pm[i]) : 0.f;
+            bv[i] = (n0 + nn[i] < g.N && k0 + kb[i] < kend) ? load_b<MODE, KS>(g, k0 + kb[i], n0 + nn[i]) : 0.f;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            int mm, kk;
-            if (Traits<MODE>::a_kfast) { kk = tid & 15; mm = (tid >> 4) + 16 * i; }
-            else { mm = tid & 63; kk = (tid >> 6) + 4 * i; }
-            As[kk][mm] = (m0 + mm < g.M && k0 + kk < kend) ? load_a<MODE>(g, m0 + mm, k0 + kk) : 0.f;
-            int nn, kb;
-            if (Traits<MODE>::b_kfast) { kb = tid & 15; nn = (tid >> 4) + 16 * i; }
-            else { nn = tid & 63; kb = (tid >> 6) + 4 * i; }
-            Bs[kb][nn] = (n0 + nn < g.N && k0 + kb < kend) ? load_b<MODE>(g, k0 + kb, n0 + nn) : 0.f;
+            As[ka[i]][mm[i]] = av[i];
+            Bs[kb[i]][nn[i]] = bv[i];
         }
         __syncthreads();
 #pragma unroll
@@ -257,17 +286,19 @@ int gemm(int mode, const Gemm& q, hipStream_t s) {
     VAE_CHECK(grid.y < 65536 && grid.z < 65536, "f32 gemm: grid too large");
     {
         ProfScope prof("gemm_f32_kernel", 2.0 * (double)M * (double)N * (double)K, 0.0, s);
+#define GO(M, K) hipLaunchKernelGGL((gemm_f32_kernel<M, K>), grid, dim3(256), 0, s, g)
         switch (mode) {
-            case CONV_FWD: hipLaunchKernelGGL((gemm_f32_kernel<CONV_FWD>), grid, dim3(256), 0, s, g); break;
-            case CONV_DGRAD: hipLaunchKernelGGL((gemm_f32_kernel<CONV_DGRAD>), grid, dim3(256), 0, s, g); break;
-            case CONV_WGRAD: hipLaunchKernelGGL((gemm_f32_kernel<CONV_WGRAD>), grid, dim3(256), 0, s, g); break;
-            case CONVT_FWD: hipLaunchKernelGGL((gemm_f32_kernel<CONVT_FWD>), grid, dim3(256), 0, s, g); break;
-            case CONVT_DGRAD: hipLaunchKernelGGL((gemm_f32_kernel<CONVT_DGRAD>), grid, dim3(256), 0, s, g); break;
-            case CONVT_WGRAD: hipLaunchKernelGGL((gemm_f32_kernel<CONVT_WGRAD>), grid, dim3(256), 0, s, g); break;
-            case LIN_FWD: hipLaunchKernelGGL((gemm_f32_kernel<LIN_FWD>), grid, dim3(256), 0, s, g); break;
-            case LIN_DGRAD: hipLaunchKernelGGL((gemm_f32_kernel<LIN_DGRAD>), grid, dim3(256), 0, s, g); break;
-            default: hipLaunchKernelGGL((gemm_f32_kernel<LIN_WGRAD>), grid, dim3(256), 0, s, g); break;
+            case CONV_FWD: if (g.ks == 3) GO(CONV_FWD, 3); else GO(CONV_FWD, 1); break;
+            case CONV_DGRAD: if (g.ks == 3) GO(CONV_DGRAD, 3); else GO(CONV_DGRAD, 1); break;
+            case CONV_WGRAD: if (g.ks == 3) GO(CONV_WGRAD, 3); else GO(CONV_WGRAD, 1); break;
+            case CONVT_FWD: GO(CONVT_FWD, 1); break;
+            case CONVT_DGRAD: GO(CONVT_DGRAD, 1); break;
+            case CONVT_WGRAD: GO(CONVT_WGRAD, 1); break;
+            case LIN_FWD: GO(LIN_FWD, 1); break;
+            case LIN_DGRAD: GO(LIN_DGRAD, 1); break;
+            default: GO(LIN_WGRAD, 1); break;
         }
+#undef GO
         VAE_LAUNCH_CHECK("gemm_f32_kernel");
     }
     if (splits > 1) {
