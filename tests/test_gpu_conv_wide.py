@@ -12,8 +12,11 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def conv(mode, x, w, b, n, H, Ci, Co):
+def conv(mode, x, w, b, n, H, Ci, Co, ws64=1):
+    """mode: conv3_wide setting; ws64: conv3_ws64 setting (1 = never: the comparisons below are between the 4-wave
+    and 8-wave kernels unless a test asks for the weight-stationary one)."""
     L.call("vae_set_tuning", b"conv3_wide", mode)
+    L.call("vae_set_tuning", b"conv3_ws64", ws64)
     try:
         rows = L.call("vae_conv3x3_stat_rows", n, H, H, Ci, Co)
         y = torch.empty(n, H, H, Co, device=DEV, dtype=torch.bfloat16)
@@ -25,6 +28,7 @@ def conv(mode, x, w, b, n, H, Ci, Co):
         return y, ss[:rows].sum(0), sq[:rows].sum(0)
     finally:
         L.call("vae_set_tuning", b"conv3_wide", 0)
+        L.call("vae_set_tuning", b"conv3_ws64", 0)
 
 
 # (images, H = W, Cin, Cout): several tiles per workgroup with one and two channel chunks; one tile per workgroup with
@@ -71,3 +75,41 @@ def test_split_k_inside_the_workgroup_equals_the_plain_form(n, H, Ci, Co):
     assert ((y1.float() - y2.float()).norm() / y1.float().norm()).item() <= 2e-4      # a bf16 rounding flips on ~1e-4 of the elements
     assert ((s1 - s2).abs().max() / s1.abs().max()).item() <= 1e-5
     assert ((q1 - q2).abs().max() / q1.abs().max()).item() <= 1e-5
+
+
+# (images, H = W, Cout) at 64 input channels: many tiles per workgroup (the first block's second conv and its input
+# gradient at batch 512), two channel tiles (the second block's first conv), 16-wide images (whole images inside a
+# tile), fewer tiles than CUs, one tile only
+@pytest.mark.parametrize("n,H,Co", [(512, 32, 64), (512, 16, 128), (64, 32, 64), (3, 16, 192), (1, 16, 64), (20, 32, 128)])
+def test_weight_stationary_kernel_equals_the_four_wave_kernel_and_torch(n, H, Co):
+    """conv3_ws64_kernel (weights resident in LDS, 64 input channels) runs the same MFMA chain per output element as
+    the 4-wave kernel: equal bf16 outputs bit for bit, statistics equal to fp32 rounding; with and without the
+    statistics / bias arguments (the input-gradient launches pass neither)."""
+    L.load()
+    Ci = 64
+    g = torch.Generator(device=DEV).manual_seed(H * 1000 + Co + n)
+    x = torch.randn(n, H, H, Ci, device=DEV, generator=g).to(torch.bfloat16)
+    w = (torch.randn(Co, 9, Ci, device=DEV, generator=g) * 0.05).to(torch.bfloat16)
+    b = torch.randn(Co, device=DEV, generator=g)
+    y4, s4, q4 = conv(1, x, w, b, n, H, Ci, Co, ws64=1)
+    yw, sw, qw = conv(1, x, w, b, n, H, Ci, Co, ws64=2)
+    assert torch.equal(y4, yw)
+    assert ((s4 - sw).abs().max() / s4.abs().max()).item() <= 1e-5
+    assert ((q4 - qw).abs().max() / q4.abs().max()).item() <= 1e-5
+    wt = w.float().view(Co, 3, 3, Ci).permute(0, 3, 1, 2).contiguous()
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), wt, b, padding=1).permute(0, 2, 3, 1)
+    assert ((yw.float() - ref).norm() / ref.norm()).item() <= 3e-3
+    # no bias, no statistics
+    outs = []
+    for ws in (1, 2):
+        L.call("vae_set_tuning", b"conv3_wide", 1)
+        L.call("vae_set_tuning", b"conv3_ws64", ws)
+        try:
+            y = torch.empty(n, H, H, Co, device=DEV, dtype=torch.bfloat16)
+            L.call("vae_conv3x3_gemm", x.data_ptr(), w.data_ptr(), None, y.data_ptr(), None, None, n, H, H, Ci, Co, L.current_stream())
+            torch.cuda.synchronize()
+            outs.append(y)
+        finally:
+            L.call("vae_set_tuning", b"conv3_wide", 0)
+            L.call("vae_set_tuning", b"conv3_ws64", 0)
+    assert torch.equal(outs[0], outs[1])

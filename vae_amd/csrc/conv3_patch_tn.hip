@@ -709,8 +709,253 @@ __global__ __launch_bounds__(512, 2) void conv3_wide_kernel(const PatchTN p) {
     }
 }
 
+
+// ============================================================================================================
+// The weight-stationary form for layers with 64 input channels: 256 pixels x 64 output channels per tile, ONE
+// workgroup of 512 threads per CU.
+//
+// With 64 input channels a tile is only nine K-steps deep, so in the kernels above the per-tile costs -- nine weight
+// tiles fetched again for every tile (72 KB against a 43 KB patch), a barrier per K-step, the fill of the copy ring --
+// outweigh the matrix work (0.26-0.30 of the matrix-pipe peak at batch 512).  Here the whole [64][9][64] weight block
+// of the workgroup's output channels (72 KB) is copied to LDS ONCE and stays; per tile only the patch moves, into
+// the other of two patch buffers while the current one is being multiplied, and the nine taps run with no barrier and
+// no copy between them: three barriers per tile instead of eleven.  Eight waves of 64 pixels x 32 channels (4 x 2
+// fragments: six fragment reads per eight matrix instructions).
+// The sum over k runs in the same order as in the other two kernels (tap by tap, two k-steps of 32 each; the bias joins
+// after it), so the three give the same bits.
+constexpr int WS_BM = 256, WS_BN = 64;
+
+// NW = 8 (the form that is launched): waves of 64 pixels x 32 channels, two per SIMD.  NW = 4: waves of 64 x 64 (eight
+// fragment reads per sixteen matrix instructions instead of six per eight: a third less LDS traffic), one per SIMD with
+// the whole register file -- measured 10 % slower (0.132 against 0.119 ms for the three launches of a step at batch 512).
+template <int W, int NW>
+__global__ __launch_bounds__(64 * NW, NW / 4) void conv3_ws64_kernel(const PatchTN p) {
+    constexpr int NT = 64 * NW;                                  // threads
+    constexpr int WS_QP = (pt_rows(W, WS_BM) / 8 + NW - 1) / NW; // patch pieces per wave
+    constexpr int W2 = W + 2;
+    constexpr int QROWS = pt_rows(W, WS_BM);
+    constexpr int Q_BYTES = QROWS * PT_ROWB;
+    constexpr int QPIECES = QROWS / 8;
+    static_assert(QROWS % 8 == 0 && QPIECES <= NW * WS_QP, "patch pieces per wave");
+    constexpr int TAP_BYTES = WS_BN * PT_ROWB;                   // one tap's 64 weight rows
+    constexpr int WBASE = 2 * Q_BYTES, DUMMY = WBASE + 9 * TAP_BYTES, TOTAL = DUMMY + 1024;
+    static_assert(TOTAL <= 163840, "LDS budget");
+    constexpr int OROW = WS_BN * 2 + 16;
+    static_assert(WS_BM * OROW <= Q_BYTES, "output tile does not fit a patch buffer");
+    static_assert(2 * 4 * WS_BN * 4 <= Q_BYTES, "statistics fold does not fit a patch buffer");
+    constexpr int NF = 4, NJ = NW == 8 ? 2 : 4, NE = 4;          // pixel fragments, channel fragments, registers per fragment
+    constexpr int CW = NJ * 16;                                  // channels per wave
+    __shared__ __attribute__((aligned(16))) unsigned char smem[TOTAL];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = NW == 8 ? wave >> 1 : wave, wn = NW == 8 ? wave & 1 : 0;     // wave tile: pixels [64 wm, +64) x channels [CW wn, +CW)
+    const int n0 = blockIdx.y * WS_BN;
+    const int ntiles = p.M / WS_BM;
+    constexpr unsigned OOB = 0xFFFFFFFFu;
+    const unsigned rowb = 128;                                   // 64 input channels
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)((unsigned)p.M * rowb), 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)((unsigned)p.N * 576u * 2u), 0x00020000);
+    auto tile_h0 = [&](int m0t) { return p.G == 1 ? ((m0t >> p.wshift) & (p.H - 1)) : 0; };
+
+    // ---- the weight block: piece q = rows [8 q, +8) of [tap][channel], 72 pieces, 72 / NW per wave
+#pragma unroll
+    for (int i = 0; i < 72 / NW; ++i) {
+        const int q = wave + NW * i;
+        const int r = q * 8 + (lane >> 3), tap = r >> 6, n = r & 63;
+        const int chunk = (lane & 7) ^ ((n >> 1) & 7);
+        const unsigned off = ((unsigned)(n0 + n) * 576u + (unsigned)tap * 64u + chunk * 8) * 2u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (lptr_t)(smem + WBASE + q * 1024), 16, (int)off, 0, 0, 0);
+    }
+
+    // ---- patch pieces of this wave: piece (wave + 8 i) = patch rows [8 (wave + 8 i), +8), lane -> (row, 16-byte chunk)
+    int q_st[WS_QP];
+#pragma unroll
+    for (int i = 0; i < WS_QP; ++i) {
+        const int prow = (wave + NW * i) * 8 + (lane >> 3);
+        const int per = (p.R + 2) * W2;
+        const int g = p.G == 1 ? 0 : (int)(((float)prow + 0.5f) * p.inv_per);
+        const int rem = prow - g * per;
+        const int rr = (int)(((float)rem + 0.5f) * (1.0f / W2)), xx = rem - rr * W2;
+        int st = ((lane & 7) ^ pt_swz(xx)) << 18;
+        if (prow < p.PR && xx >= 1 && xx <= W) st |= ((g * p.R + (rr - 1)) * W + (xx - 1) + 256) | (rr << 10) | (1 << 24);
+        q_st[i] = st;
+    }
+    // every wave issues WS_QP copies per patch (a piece past the patch, or a patch that does not exist, is a zero-fill
+    // into the dummy kilobyte), so the counted waits below are compile-time constants
+    auto stage_piece = [&](int i, int buf, int m0t, int h0t, bool valid) {
+        int st = q_st[i];
+        asm volatile("" : "+v"(st));
+        const int m = m0t + (st & 1023) - 256, r = ((st >> 10) & 255) - 1;
+        const bool ok = valid && (st >> 24) && (unsigned)(h0t + r) < (unsigned)p.H && (unsigned)m < (unsigned)p.M;
+        const unsigned off = ok ? (unsigned)m * rowb + (unsigned)((st >> 14) & 0x70) : OOB;
+        const int piece = wave + NW * i;
+        const int dst = piece < QPIECES ? buf * Q_BYTES + piece * 1024 : DUMMY;      // wave-uniform
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lptr_t)(smem + dst), 16, (int)off, 0, 0, 0);
+    };
+    int tile = blockIdx.x;
+    {
+        const int m0t = tile * WS_BM, h0t = tile_h0(m0t);
+#pragma unroll
+        for (int i = 0; i < WS_QP; ++i) stage_piece(i, 0, m0t, h0t, true);
+    }
+
+    // ---- fragment addresses (patch buffer 0; += / -= Q_BYTES when the buffers swap)
+    int a_addr[NF][3];
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+        const int ml = wm * 64 + i * 16 + (lane & 15);
+        const int g = ml >> p.rwshift, kr = ml & ((1 << p.rwshift) - 1);
+        const int r = kr >> p.wshift, x = kr & (W - 1);
+        const int prow = (g * (p.R + 2) + r) * W2 + x + 1;            // the pixel one image row up
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+            a_addr[i][d] = (prow + d - 1) * PT_ROWB + (((lane >> 4) ^ pt_swz(x + d)) << 4);
+    }
+    int b_addr[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int row = wn * CW + j * 16 + (lane & 15);
+        b_addr[j] = WBASE + row * PT_ROWB + (((lane >> 4) ^ ((row >> 1) & 7)) << 4);
+    }
+    auto chan = [&](int j, int e) { return wn * CW + j * 16 + (lane >> 4) * 4 + e; };      // channel of the tile
+    float bv[NJ][NE];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < NE; ++e) bv[j][e] = p.bias ? p.bias[n0 + chan(j, e)] : 0.f;
+    float ssum[NJ][NE], ssq[NJ][NE];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < NE; ++e) ssum[j][e] = ssq[j][e] = 0.f;
+    const bool want_stats = p.stat_sum != nullptr;
+
+    int pbuf = 0;
+    bool first = true;
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int m0 = tile * WS_BM;
+        // this tile's patch (and, the first time, the weights and the bias) has landed; the stores of the previous
+        // tile's epilogue (2048 / NT per thread) are younger and may still be in flight
+        if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2048 / NT) : "memory");
+        first = false;
+        barrier_keep_copies();
+        {   // the next tile's patch goes into the other buffer (last read by the previous epilogue, behind the barrier)
+            const int nt = tile + (int)gridDim.x;
+            const int nm0 = nt * WS_BM, nh0 = tile_h0(nm0);
+#pragma unroll
+            for (int i = 0; i < WS_QP; ++i) stage_piece(i, pbuf ^ 1, nm0, nh0, nt < ntiles);
+        }
+        f32x4 acc[NF][NJ];
+#pragma unroll
+        for (int i = 0; i < NF; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dh = tap / 3, dw = tap % 3;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 xa[NF], wb[NJ];
+#pragma unroll
+                for (int i = 0; i < NF; ++i) {
+                    int a = a_addr[i][dw];
+                    if (ks) asm volatile("v_xor_b32 %0, 64, %1" : "=v"(a) : "v"(a_addr[i][dw]));
+                    xa[i] = *(const bf16x8*)(smem + a + dh * W2 * PT_ROWB);
+                }
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    int b = b_addr[j];
+                    if (ks) asm volatile("v_xor_b32 %0, 64, %1" : "=v"(b) : "v"(b_addr[j]));
+                    wb[j] = *(const bf16x8*)(smem + b + tap * TAP_BYTES);
+                }
+#pragma unroll
+                for (int i = 0; i < NF; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
+            }
+        }
+        // ---- epilogue: bias and statistics in registers, the bf16 tile through the patch buffer just consumed
+#pragma unroll
+        for (int i = 0; i < NF; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    const float v = acc[i][j][e] + bv[j][e];
+                    acc[i][j][e] = v;
+                    ssum[j][e] += v;
+                    ssq[j][e] += v * v;
+                }
+        const unsigned stg = (unsigned)(size_t)(lptr_t)smem + (unsigned)(pbuf * Q_BYTES);     // LDS byte address
+        barrier_keep_copies();                       // every wave has read the last tap of that patch
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            const int ml = wm * 64 + i * 16 + (lane & 15);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                lds_store_b64(stg + ml * OROW + chan(j, 0) * 2, pack2bf(acc[i][j][0], acc[i][j][1]), pack2bf(acc[i][j][2], acc[i][j][3]));
+        }
+        barrier_keep_copies();
+        {
+            // 2048 16-byte pieces (256 rows x 8): piece (row, tid & 7), rows tid >> 3 + (NT / 8) * q
+            constexpr int RS = NT / 8;                 // rows one pass of the workgroup covers
+            u32x4 v[2048 / NT];
+            const unsigned a = stg + (tid >> 3) * OROW + (tid & 7) * 16;
+#pragma unroll
+            for (int h = 0; h < 2048 / NT / 4; ++h)
+                lds_load4_b128(a + (4 * h) * RS * OROW, a + (4 * h + 1) * RS * OROW, a + (4 * h + 2) * RS * OROW,
+                               a + (4 * h + 3) * RS * OROW, v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]);
+            bf16_t* o = p.out + (long)(m0 + (tid >> 3)) * p.N + n0 + (tid & 7) * 8;
+#pragma unroll
+            for (int q = 0; q < 2048 / NT; ++q) *(u32x4*)(o + (long)q * RS * p.N) = v[q];
+        }
+        pbuf ^= 1;
+        const int delta = pbuf ? Q_BYTES : -Q_BYTES;
+#pragma unroll
+        for (int i = 0; i < NF; ++i)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) a_addr[i][d] += delta;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // copies requested past the last tile land before LDS is released
+
+    if (want_stats) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                ssum[j][e] = pt_row16_sum(ssum[j][e]);
+                ssq[j][e] = pt_row16_sum(ssq[j][e]);
+            }
+        float* red = (float*)smem;                   // [sum | sum of squares][wave row][channel], in patch buffer 0
+        barrier_keep_copies();                       // the last tile's staged rows have been read
+        if ((lane & 15) == 0) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    red[wm * WS_BN + chan(j, e)] = ssum[j][e];
+                    red[(4 + wm) * WS_BN + chan(j, e)] = ssq[j][e];
+                }
+        }
+        barrier_keep_copies();
+        if (tid < WS_BN) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { s += red[w * WS_BN + tid]; q += red[(4 + w) * WS_BN + tid]; }
+            p.stat_sum[(long)blockIdx.x * p.N + n0 + tid] = s;
+            p.stat_sq[(long)blockIdx.x * p.N + n0 + tid] = q;
+        }
+    }
+}
+
 // 0: choose per launch, 1: always the 4-wave kernel, 2: the 8-wave kernel wherever its geometry allows
 int g_conv3_wide_mode = 0;
+// 0: the weight-stationary kernel for 64-input-channel launches that fill the chip, 1: never, 2: wherever its geometry allows
+int g_conv3_ws64_mode = 0;
 // 0: choose per launch, 1: never split K inside the workgroup, 2: wherever the chunk count is even
 int g_conv3_ksplit_mode = 0;
 unsigned long long* g_conv3_dbg = nullptr;      // diagnostic: where the stamping instantiation writes (vae_set_debug_buffer)
@@ -763,12 +1008,28 @@ bool conv3_patch_tn_ok(int n_img, int H, int W, int Cin, int Cout) {
 // ceil(tiles / gx) pixel tiles and leave one row of partial statistics.
 struct PtPlan {
     int bm, bn, gx, gy, ks;
-    bool wide;
+    bool wide, ws64;
 };
 static PtPlan pt_plan(long M, int H, int W, int Cin, int Cout) {
     PtPlan q;
     q.wide = false;
+    q.ws64 = false;
     q.ks = 1;
+    // 64 input channels: the weight-stationary kernel (whole 256-pixel tiles, 16- or 32-wide images: the widths whose
+    // two patch buffers fit beside the 72 KB weight block), where its jobs give every CU a workgroup
+    if (g_conv3_ws64_mode != 1 && Cin == 64 && (W == 16 || W == 32) && Cout % WS_BN == 0 && M % WS_BM == 0 &&
+        pt_geom_ok(H, W, WS_BM)) {
+        const long jobs = M / WS_BM * (Cout / WS_BN);
+        if (jobs >= 256 || g_conv3_ws64_mode == 2) {
+            q.ws64 = true;
+            q.bm = WS_BM; q.bn = WS_BN; q.gy = Cout / WS_BN;
+            long gx = 256 / q.gy;
+            if (gx < 1) gx = 1;
+            if (gx > M / WS_BM) gx = M / WS_BM;
+            q.gx = (int)gx;
+            return q;
+        }
+    }
     // the 8-wave kernel: whole 256-pixel x 128-channel tiles only, one workgroup per CU; worth it when its jobs
     // fill at least three quarters of the chip
     if (g_conv3_wide_mode != 1 && W >= 8 && Cout % WD_BN == 0 && M % WD_BM == 0 && pt_geom_ok(H, W, WD_BM)) {
@@ -817,6 +1078,13 @@ int conv3_patch_tn_launch(const void* x, const void* w_packed, const float* bias
     p.inv_per = 1.0f / (float)((p.R + 2) * (W + 2));
     VAE_CHECK(p.PR <= pt_rows(W, plan.bm) && p.rwshift >= 0, "conv3 patch kernel: internal geometry error (PR=%d)", p.PR);
     dim3 grid(plan.gx, plan.gy);
+    if (plan.ws64) {
+        ProfScope prof("conv3_ws64_kernel", flops, bytes, s);
+        if (W == 16) hipLaunchKernelGGL((conv3_ws64_kernel<16, 8>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((conv3_ws64_kernel<32, 8>), grid, dim3(512), 0, s, p);
+        VAE_LAUNCH_CHECK("conv3_ws64_kernel");
+        return 0;
+    }
     if (plan.wide) {
         ProfScope prof("conv3_wide_kernel", flops, bytes, s);
 #define WIDE_V(V)                                                                                      \
