@@ -23,6 +23,8 @@ def bench_name(rocprof_name: str):
         return f"conv3_patch_tn_kernel<{m.group(1)}" + (",ksplit>" if m.group(2) == "2" else ">")
     if "conv3_wide_kernel" in n:
         return "conv3_wide_kernel"
+    if "conv3_ws64_kernel" in n:
+        return "conv3_ws64_kernel"
     if "conv3_wgrad_patch_kernel" in n:
         return "conv3_wgrad_patch_kernel"
     m = re.search(r"gemm_tn_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), \d+>", n)
