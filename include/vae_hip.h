@@ -60,7 +60,7 @@ int vae_prof_stop(char* names, int* launches, double* total_ms, double* flops, d
  * always, 2 the streaming kernel wherever its geometry allows (the *_stat_rows functions follow the setting); "wgrad_pc" =
  * 0 the conv3x3 weight gradient with separate copying and computing waves for long K ranges (default), 1 always, 2 never; "conv3_ws64" =
  * 0 the weight-stationary conv3x3 kernel for launches with 64 input channels whose tiles fill the chip (default), 1 never, 2 wherever
- * its geometry allows (16- or 32-wide images, whole 256-pixel tiles).  Not thread-safe: set it while nothing is being
+ * its geometry allows (16- or 32-wide images, whole 256-pixel tiles), 3 as 0 with a hand-pipelined K loop (faster alone, not in the step on every box).  Not thread-safe: set it while nothing is being
  * launched. */
 int vae_set_tuning(const char* key, int value);
 /* Diagnostic aid: device buffer (>= 128 bytes per workgroup of the launch under study) that the diagnostic kernel

@@ -94,6 +94,9 @@ def test_weight_stationary_kernel_equals_the_four_wave_kernel_and_torch(n, H, Co
     y4, s4, q4 = conv(1, x, w, b, n, H, Ci, Co, ws64=1)
     yw, sw, qw = conv(1, x, w, b, n, H, Ci, Co, ws64=2)
     assert torch.equal(y4, yw)
+    if n * H * H * (Co // 64) >= 256 * 256:              # mode 3 = mode 0 (launches that fill the chip) with the pipelined K loop
+        yp, sp, qp = conv(1, x, w, b, n, H, Ci, Co, ws64=3)
+        assert torch.equal(y4, yp) and torch.equal(sw, sp) and torch.equal(qw, qp)
     assert ((s4 - sw).abs().max() / s4.abs().max()).item() <= 1e-5
     assert ((q4 - qw).abs().max() / q4.abs().max()).item() <= 1e-5
     wt = w.float().view(Co, 3, 3, Ci).permute(0, 3, 1, 2).contiguous()

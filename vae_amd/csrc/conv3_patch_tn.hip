@@ -728,7 +728,7 @@ constexpr int WS_BM = 256, WS_BN = 64;
 // NW = 8 (the form that is launched): waves of 64 pixels x 32 channels, two per SIMD.  NW = 4: waves of 64 x 64 (eight
 // fragment reads per sixteen matrix instructions instead of six per eight: a third less LDS traffic), one per SIMD with
 // the whole register file -- measured 10 % slower (0.132 against 0.119 ms for the three launches of a step at batch 512).
-template <int W, int NW>
+template <int W, int NW, bool PIPE>
 __global__ __launch_bounds__(64 * NW, NW / 4) void conv3_ws64_kernel(const PatchTN p) {
     constexpr int NT = 64 * NW;                                  // threads
     constexpr int WS_QP = (pt_rows(W, WS_BM) / 8 + NW - 1) / NW; // patch pieces per wave
@@ -853,29 +853,51 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv3_ws64_kernel(const Patch
         for (int i = 0; i < NF; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // the 18 half-steps (tap, 32-channel half) of the tile.  PIPE: software-pipelined by hand -- the fragments of
+        // half-step h + 1 are requested before the matrix instructions of half-step h are issued (the compiler, left
+        // alone, emits "six reads, wait, eight matrix instructions" per half-step).  Measured at batch 512: the kernel
+        // itself 4 % faster (0.116 -> 0.112 ms for the three launches of a step), the train step 8 us faster on the
+        // boxes of the pool that run it in 1.53-1.56 ms and 24-30 us SLOWER on those that run it in 1.57-1.62 ms, with
+        // no kernel longer in the trace: the step there follows the energy a kernel draws, not its duration.  The
+        // launcher therefore takes the plain form; PIPE stays selectable (tuning key conv3_ws64 = 3).
+        bf16x8 xa[2][NF], wb[2][NJ];
+        auto fetch = [&](int h, int buf) {
+            const int tap = h >> 1, ks = h & 1, dh = tap / 3, dw = tap % 3;
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int dh = tap / 3, dw = tap % 3;
+            for (int i = 0; i < NF; ++i) {
+                int a = a_addr[i][dw];
+                if (ks) asm volatile("v_xor_b32 %0, 64, %1" : "=v"(a) : "v"(a_addr[i][dw]));
+                xa[buf][i] = *(const bf16x8*)(smem + a + dh * W2 * PT_ROWB);
+            }
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 xa[NF], wb[NJ];
+            for (int j = 0; j < NJ; ++j) {
+                int b = b_addr[j];
+                if (ks) asm volatile("v_xor_b32 %0, 64, %1" : "=v"(b) : "v"(b_addr[j]));
+                wb[buf][j] = *(const bf16x8*)(smem + b + tap * TAP_BYTES);
+            }
+        };
+        if (PIPE) {
+            fetch(0, 0);
 #pragma unroll
-                for (int i = 0; i < NF; ++i) {
-                    int a = a_addr[i][dw];
-                    if (ks) asm volatile("v_xor_b32 %0, 64, %1" : "=v"(a) : "v"(a_addr[i][dw]));
-                    xa[i] = *(const bf16x8*)(smem + a + dh * W2 * PT_ROWB);
-                }
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    int b = b_addr[j];
-                    if (ks) asm volatile("v_xor_b32 %0, 64, %1" : "=v"(b) : "v"(b_addr[j]));
-                    wb[j] = *(const bf16x8*)(smem + b + tap * TAP_BYTES);
-                }
+            for (int h = 0; h < 18; ++h) {
+                if (h + 1 < 18) fetch(h + 1, (h + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);       // the scheduler must not sink the reads back below the matrix instructions
 #pragma unroll
                 for (int i = 0; i < NF; ++i)
 #pragma unroll
                     for (int j = 0; j < NJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[h & 1][j], xa[h & 1][i], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int h = 0; h < 18; ++h) {
+                fetch(h, 0);
+#pragma unroll
+                for (int i = 0; i < NF; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[0][j], xa[0][i], acc[i][j], 0, 0, 0);
             }
         }
         // ---- epilogue: bias and statistics in registers, the bf16 tile through the patch buffer just consumed
@@ -954,7 +976,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv3_ws64_kernel(const Patch
 
 // 0: choose per launch, 1: always the 4-wave kernel, 2: the 8-wave kernel wherever its geometry allows
 int g_conv3_wide_mode = 0;
-// 0: the weight-stationary kernel for 64-input-channel launches that fill the chip, 1: never, 2: wherever its geometry allows
+// 0: the weight-stationary kernel for 64-input-channel launches that fill the chip, 1: never, 2: wherever its geometry allows,
+// 3: as 0 with the hand-pipelined K loop (PIPE = true; see the kernel)
 int g_conv3_ws64_mode = 0;
 // 0: choose per launch, 1: never split K inside the workgroup, 2: wherever the chunk count is even
 int g_conv3_ksplit_mode = 0;
@@ -1080,8 +1103,13 @@ int conv3_patch_tn_launch(const void* x, const void* w_packed, const float* bias
     dim3 grid(plan.gx, plan.gy);
     if (plan.ws64) {
         ProfScope prof("conv3_ws64_kernel", flops, bytes, s);
-        if (W == 16) hipLaunchKernelGGL((conv3_ws64_kernel<16, 8>), grid, dim3(512), 0, s, p);
-        else hipLaunchKernelGGL((conv3_ws64_kernel<32, 8>), grid, dim3(512), 0, s, p);
+        if (g_conv3_ws64_mode == 3) {         // the hand-pipelined K loop
+            if (W == 16) hipLaunchKernelGGL((conv3_ws64_kernel<16, 8, true>), grid, dim3(512), 0, s, p);
+            else hipLaunchKernelGGL((conv3_ws64_kernel<32, 8, true>), grid, dim3(512), 0, s, p);
+        } else {
+            if (W == 16) hipLaunchKernelGGL((conv3_ws64_kernel<16, 8, false>), grid, dim3(512), 0, s, p);
+            else hipLaunchKernelGGL((conv3_ws64_kernel<32, 8, false>), grid, dim3(512), 0, s, p);
+        }
         VAE_LAUNCH_CHECK("conv3_ws64_kernel");
         return 0;
     }
