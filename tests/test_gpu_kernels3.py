@@ -172,3 +172,30 @@ def test_multi_pack_transposing_jobs(L, L_, C, hw):
     assert torch.equal(fc_d.float().cpu()[:, :, :L_], bf(w3.permute(2, 1, 0)))
     assert float(fc_d.float().abs().cpu()[:, :, L_:].max()) == 0.0
     assert torch.equal(up_d.float().cpu(), bf(w_up.view(C, hw, L_).permute(2, 1, 0)))
+
+
+@pytest.mark.parametrize("Co,Ci", [(64, 64), (256, 128), (72, 24), (128, 8)])
+def test_multi_pack_first_dim_to_fastest_jobs(L, Co, Ci):
+    """the conv weights packed for the input-gradient GEMMs ([co][ci][tap] -> [ci][8 - tap][co], the flipped kernel of
+    vae/models/vae.py:20's Conv2d backward) and the ConvTranspose weights ([ci][co][tap] -> [tap][co][ci],
+    vae/models/vae.py:131): the source's first dim becomes the destination's fastest one and the source's fastest dim
+    (9 or 4 taps) is too short for a tile of its own, so the inner dims are tiled as one run.  Sizes include ragged
+    tile edges (72 rows, runs of 216 and 96).  bf16 of the permuted source, exactly."""
+    g = torch.Generator().manual_seed(Co * 7 + Ci)
+    w = torch.randn(Co, Ci, 3, 3, generator=g)
+    wt = torch.randn(Co, Ci, 2, 2, generator=g)        # a ConvTranspose weight [in = Co][out = Ci][2][2]
+    wd, wtd = w.to(DEV), wt.to(DEV)
+    conv_d = torch.zeros(Ci, 9, Co, device=DEV, dtype=torch.bfloat16)
+    ct_f = torch.zeros(4, Ci, Co, device=DEV, dtype=torch.bfloat16)
+
+    class Job(ctypes.Structure):
+        _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("dims", ctypes.c_long * 4),
+                    ("strides", ctypes.c_long * 4), ("base", ctypes.c_long), ("f32", ctypes.c_int)]
+    l4 = lambda *v: (ctypes.c_long * 4)(*v)
+    jobs = (Job * 2)()
+    jobs[0] = Job(wd.data_ptr(), conv_d.data_ptr(), l4(Co, Ci, 9, 1), l4(1, 9 * Co, -Co, 0), 8 * Co, 0)
+    jobs[1] = Job(wtd.data_ptr(), ct_f.data_ptr(), l4(Co, Ci, 4, 1), l4(1, Co, Ci * Co, 0), 0, 0)
+    L.call("vae_multi_pack", jobs, 2, L.current_stream())
+    bf = lambda t: t.to(torch.bfloat16).float()
+    assert torch.equal(conv_d.float().cpu(), bf(w.view(Co, Ci, 9).flip(2).permute(1, 2, 0)))
+    assert torch.equal(ct_f.float().cpu(), bf(wt.view(Co, Ci, 4).permute(2, 1, 0)))

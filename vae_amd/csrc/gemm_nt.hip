@@ -369,7 +369,7 @@ struct PackJob {
     int vec8;            // innermost destination run is contiguous and a multiple of 8
     // tiled form (a transposition: the source's fastest dim is not the destination's): 64 x 32 tiles through LDS,
     // read along the source's fastest dim `si`, written along the destination's fastest dim `di`
-    int tiled, si, di, r0, r1;            // r0, r1: the two other dims
+    int tiled, si, di, r0, r1;            // tiled: 0 gather, 1 tiles over (di, si), 2 tiles over (dim 0, inner run); r0, r1: the two other dims
     int dim[4];                           // sizes in SOURCE order
     long dst_stride[4];                   // destination strides in source order (dst_stride[di] == 1)
     int tiles_d, tiles_s;
@@ -421,10 +421,46 @@ __device__ __forceinline__ void pack_tiled(const PackJob& jb, float (*tile)[33])
     }
 }
 
+// The same turn for a job whose FIRST source dim is the destination's fastest while the source's own fastest dim is
+// short (the conv weights for the input-gradient GEMMs: [co][ci][tap] -> [ci][8 - tap][co]; the ConvTranspose weights
+// [ci][co][tap] -> [tap][co][ci]): the three inner source dims are read as one contiguous run of Q = d1 * d2 * d3
+// floats per row, and a tile's 32 positions of that run are taken apart again for the destination offset.
+__device__ __forceinline__ void pack_tiled_flat(const PackJob& jb, float (*tile)[33]) {
+    const int D0 = jb.dim[0], Q = jb.dim[1] * jb.dim[2] * jb.dim[3];
+    const int ntile = jb.tiles_d * jb.tiles_s;
+    for (int t = blockIdx.x; t < ntile; t += gridDim.x) {
+        const int d0 = (t / jb.tiles_s) * 64, s0 = (t % jb.tiles_s) * 32;
+        {
+            const int sl = threadIdx.x & 31, dl = threadIdx.x >> 5;
+#pragma unroll
+            for (int ps = 0; ps < 8; ++ps) {
+                const int d = d0 + dl + 8 * ps, sx = s0 + sl;
+                tile[dl + 8 * ps][sl] = (d < D0 && sx < Q) ? jb.src[(long)d * Q + sx] : 0.f;
+            }
+        }
+        __syncthreads();
+        {
+            const int d8 = (threadIdx.x & 7) * 8, sl = threadIdx.x >> 3;
+            const int sx = s0 + sl;
+            if (sx < Q && d0 + d8 < D0) {                              // dim[0] % 8 == 0 (checked on the host)
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = tile[d8 + k][sl];
+                const int i3 = sx % jb.dim[3], r = sx / jb.dim[3];
+                const int i2 = r % jb.dim[2], i1 = r / jb.dim[2];
+                const long d = jb.base + i1 * jb.dst_stride[1] + i2 * jb.dst_stride[2] + i3 * jb.dst_stride[3] + d0 + d8;
+                *(uint4*)((bf16_t*)jb.dst + d) = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+            }
+        }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void multi_pack_kernel(const PackJobs jobs) {
     __shared__ float tile[64][33];
     const PackJob& jb = jobs.j[blockIdx.y];
-    if (jb.tiled) { pack_tiled(jb, tile); return; }
+    if (jb.tiled == 1) { pack_tiled(jb, tile); return; }
+    if (jb.tiled == 2) { pack_tiled_flat(jb, tile); return; }
     const int step = jb.vec8 ? 8 : 1;
     const int items = jb.n / step;
     // Workgroups go round-robin over the 8 XCDs, each with its own L2, and neighbouring destination runs gather from
@@ -717,6 +753,11 @@ extern "C" int vae_multi_pack(const vae_pack_job* jobs, int njobs, void* stream)
             q.r0 = rest[0]; q.r1 = rest[1];
             for (int k = 0; k < 4; ++k) { q.dim[k] = (int)dims[k]; q.dst_stride[k] = jobs[i].strides[k]; }
             q.tiles_d = (int)((dims[di] + 63) / 64); q.tiles_s = (int)((dims[si] + 31) / 32);
+        } else if (q.vec8 && di == 0 && si != 0 && dims[0] >= 64 && dims[0] % 8 == 0 && sstride[0] >= 32) {
+            // the inner source dims as one run (the source's fastest dim alone is too short for a tile)
+            q.tiled = 2; q.si = si; q.di = 0; q.r0 = q.r1 = 0;
+            for (int k = 0; k < 4; ++k) { q.dim[k] = (int)dims[k]; q.dst_stride[k] = jobs[i].strides[k]; }
+            q.tiles_d = (int)((dims[0] + 63) / 64); q.tiles_s = (int)((sstride[0] + 31) / 32);
         }
         const int items = q.tiled ? (int)(n / 8) : (int)(n / (q.vec8 ? 8 : 1));      // a tile holds 2048 elements = 256 items
         if (items > max_items) max_items = items;
