@@ -60,7 +60,8 @@ int vae_prof_stop(char* names, int* launches, double* total_ms, double* flops, d
  * always, 2 the streaming kernel wherever its geometry allows (the *_stat_rows functions follow the setting); "wgrad_pc" =
  * 0 the conv3x3 weight gradient with separate copying and computing waves for long K ranges (default), 1 always, 2 never; "conv3_ws64" =
  * 0 the weight-stationary conv3x3 kernel for launches with 64 input channels whose tiles fill the chip (default), 1 never, 2 wherever
- * its geometry allows (16- or 32-wide images, whole 256-pixel tiles), 3 as 0 with a hand-pipelined K loop (faster alone, not in the step on every box).  Not thread-safe: set it while nothing is being
+ * its geometry allows (16- or 32-wide images, whole 256-pixel tiles), 3 as 0 with a hand-pipelined K loop (faster alone, not in the step on every box); "conv1_bwd" = 0 the whole-model backward runs
+ * the first conv's BatchNorm backward and weight gradient as vae_bn_bwd_conv1 where Cin <= 3 (default), 1 as separate passes.  Not thread-safe: set it while nothing is being
  * launched. */
 int vae_set_tuning(const char* key, int value);
 /* Diagnostic aid: device buffer (>= 128 bytes per workgroup of the launch under study) that the diagnostic kernel
@@ -273,6 +274,21 @@ int vae_bn_act_bwd_route(const void* gin, const void* y, const float* scale, con
                          const void* route, int n_img, int H, int W, int C, int pool, double p_drop,
                          const void* keep_mask, unsigned long long seed, unsigned step,
                          unsigned stream_id, unsigned rank, void* stream);
+/* Backward of the network's first  Conv2d(Cin, 64, 3, padding=1) -> BatchNorm2d(64) -> ReLU  (vae/models/vae.py:24-31
+ * with in_channels = the image channels, vae.py:34) in one pass over gin and y.  Nothing in front of that conv takes
+ * an input gradient, so the gradient of the conv output is never stored: the kernel accumulates per channel
+ * sum(d * xhat), sum(d) (d = gin where the ReLU passed) and, on the matrix pipe, sum_p d X, sum_p y X and sum_p X against
+ * the nine shifted copies X of the input; BatchNorm's backward is affine in those, so
+ *   dW = scale * (sum d X - mean(d) sum X - mean(d xhat) * rstd * (sum y X - mean * sum X)).
+ * gin, y [n,H,W,64] bf16; x8 [n,H,W,8] bf16 (vae_nchw_to_nhwc8); scale/shift/mean/rstd [64] as left by vae_bn_finalize;
+ * scratch: vae_bn_bwd_conv1_scratch_floats(n, H, W) floats, 16-byte aligned; sums = [d gamma (64) | d beta (64)];
+ * dW [64][Cin][3][3] f32 (overwritten).  Cin <= 3 (nine taps x Cin columns must fit 32).  Same result as
+ * vae_bn_act_bwd followed by vae_wgrad_gemm(VAE_WGRAD_CONV3_C8) up to rounding: there g is rounded to bf16 before
+ * the sum over pixels, here the three sums are exact products accumulated in fp32 and folded in fp64. */
+long vae_bn_bwd_conv1_scratch_floats(int n_img, int H, int W);
+int vae_bn_bwd_conv1(const void* gin, const void* y, const void* x8, const float* scale, const float* shift,
+                     const float* mean, const float* rstd, float* scratch, float* sums, float* dW, int n_img,
+                     int H, int W, int Cin, void* stream);
 /* ---- GroupNorm form of the double-conv block: nn.GroupNorm(8, C) + ReLU (+ nn.Dropout) (+ nn.MaxPool2d(2)),
  *      vae/practice/vae_conv.py:20-36,50-59 and vae/practice/vae_original.py:58-74 ----------------------------
  * y [n,H,W,C] bf16 (a conv output) -> out [n,H,W,C] or, with pool, [n,H/2,W/2,C].  Statistics are per image and

@@ -63,6 +63,8 @@ SIGNATURES = {
     "vae_bn_act_bwd_route": (None, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_double, P,
                                     c_ulonglong, c_uint, c_uint, c_uint, P]),
     "vae_bn_act_bwd_blocks": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "vae_bn_bwd_conv1_scratch_floats": (c_long, [c_int, c_int, c_int]),
+    "vae_bn_bwd_conv1": (None, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "vae_colsum_blocks": (c_int, [c_long, c_int]),
     "vae_colsum_bf16": (None, [P, c_long, c_int, P, P, P]),
     "vae_conv1x1_out_fwd": (None, [P, P, P, P, c_int, c_int, c_int, c_int, P]),

@@ -1,0 +1,319 @@
+// Backward of the network's first layer group  Conv2d(Cin <= 3, 64, 3, padding=1) -> BatchNorm2d -> ReLU  in ONE pass
+// over the two large tensors (vae/models/vae.py:24-31, the first conv of the first DoubleConv).
+//
+// No layer in front of the first conv needs an input gradient, so the gradient g of the conv output is only ever
+// used in sums over all pixels -- and g is affine in quantities a single pass can accumulate.  With
+//   d  = gin where the ReLU passed, 0 elsewhere          (gin = gradient of the activation)
+//   xh = (y - mean) * rstd                                (y = stored conv output)
+//   g  = scale * (d - mean_p(d) - xh * mean_p(d * xh))    (BatchNorm backward, scale = gamma * rstd)
+// the weight gradient  dW[co][j] = sum_p g[p][co] * X[p][j]  (X[p][j]: input pixel p shifted by tap j / channel) is
+//   dW = scale * (T1 - mean(d) * T2 - mean(d * xh) * T3),
+//   T1[co][j] = sum_p d[p][co] X[p][j],   T2[j] = sum_p X[p][j],   T3[co][j] = rstd * (sum_p y[p][co] X[p][j] - mean * T2[j]).
+// One kernel reads gin and y once and accumulates everything on the matrix pipe -- T1, sum y X, T2 and, for d gamma
+// and d beta, sum d (a column of ones in X) and sum d * y (the diagonal of d^T y): per 64-pixel tile the bf16 values [d | y] (128 columns, d is exact in bf16:
+// it is gin or 0) and the 27 shifted input values of each pixel go to LDS, and the K = pixel contraction runs as
+// 16x16x32 MFMAs on transposing LDS reads; T2 comes from a constant all-ones operand built in registers.  Neither g
+// nor any other full-size tensor is written: against the separate BatchNorm-backward passes plus the weight-gradient
+// GEMM this drops one write and two reads of the [pixels][64] tensor and three launches.
+// Every workgroup leaves one row of partial results; vae_sum_partials folds the rows (fixed order, fp64) and a
+// one-workgroup kernel forms dW, d gamma and d beta.
+#include "common.h"
+#include "prof.h"
+#include "../../include/vae_hip.h"
+
+namespace vae {
+
+int g_conv1_bwd_mode = 0;
+
+constexpr int C1_BK = 64;                                   // pixels per tile
+constexpr int C1_ROWA = 256, C1_ROWX = 64;                  // bytes per LDS row: 64 d + 64 y | 32 shifted-input columns
+constexpr int C1_A_BYTES = C1_BK * C1_ROWA, C1_X_BYTES = C1_BK * C1_ROWX, C1_STAGE = C1_A_BYTES + C1_X_BYTES;
+constexpr int C1_COLS = 32, C1_TROWS = 129;                 // T rows: 64 x d, 64 x y, 1 x ones
+constexpr int C1_ROWF = C1_TROWS * C1_COLS + 64;            // floats per workgroup: T | sum d*y (64); sum d is column 31 of T
+constexpr int C1_MAX_BLOCKS = 768;                         // three resident workgroups per CU
+
+struct Conv1Bwd {
+    const bf16_t* gin;
+    const bf16_t* y;
+    const bf16_t* x8;
+    const float* scale;
+    const float* shift;
+    const float* mean;
+    const float* rstd;
+    float* part;
+    int npix, H, W, wshift, hshift, Cin, ntile;
+};
+
+// swizzles of the 16-byte chunk index: the 8 rows {b..b+3, b+8..b+11} one half of a transposing read touches land on
+// 8 distinct 32-byte slots of the 256-byte bank line
+__device__ __forceinline__ int c1_swz_a(int row) { return ((row & 3) | (((row >> 3) & 1) << 2)) << 1; }
+__device__ __forceinline__ int c1_swz_x(int row) { return ((row >> 3) & 1) << 1; }
+
+// lanes 16g..16g+15 fetch rows k0+8g .. k0+8g+7 of columns col0..col0+15 transposed: lane (l & 15) gets column
+// col0 + (l & 15), 8 consecutive k.  Inline asm: the caller waits with c1_wait before the first use.
+template <bool XT>
+__device__ __forceinline__ bf16x8 c1_frag(unsigned base, int k0, int col0, int lane) {
+    constexpr int ROWB = XT ? C1_ROWX : C1_ROWA;
+    const int g = lane >> 4, t = lane & 15;
+    const int row = k0 + 8 * g + (t >> 2);
+    const int off = (col0 + 4 * (t & 3)) * 2;
+    const int chunk = off >> 4, within = off & 15;
+    const int s0 = XT ? c1_swz_x(row) : c1_swz_a(row), s1 = XT ? c1_swz_x(row + 4) : c1_swz_a(row + 4);
+    const unsigned a = base + row * ROWB + (((chunk ^ s0) << 4) | within);
+    const unsigned b = base + (row + 4) * ROWB + (((chunk ^ s1) << 4) | within);
+    short4v lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3" : "=&v"(lo), "=&v"(hi) : "v"(a), "v"(b) : "memory");
+    typedef __attribute__((ext_vector_type(8))) short short8v;
+    const short8v v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ void c1_wait(bf16x8& f) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f) : : "memory"); }
+
+__global__ __launch_bounds__(256, 3) void bn_bwd_conv1_kernel(const Conv1Bwd p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * C1_STAGE];
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cg = tid & 7, pl = tid >> 3;                  // channel group (8 channels) and pixel lane (0..31) of the load phase
+    const int c0 = cg * 8;
+
+    // columns 9 * Cin .. 31 of the shifted-input tiles are never written: clear everything once
+    for (int i = tid; i < 2 * C1_STAGE / 16; i += 256) ((uint4*)smem)[i] = make_uint4(0u, 0u, 0u, 0u);
+
+    __syncthreads();
+    // column 31 is 1.0 in every row (nine taps x Cin <= 27 columns are rewritten per tile, this one never): T1[c][31] = sum d
+    if (tid < 128) {
+        const int row = tid & 63;
+        *(bf16_t*)(smem + (tid >> 6) * C1_STAGE + C1_A_BYTES + row * C1_ROWX + (((3 ^ c1_swz_x(row)) << 4) | 14)) = (bf16_t)0x3F80;
+    }
+    float sc[8], sh[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { sc[i] = p.scale[c0 + i]; sh[i] = p.shift[c0 + i]; }
+
+    // registers of the tile in flight: two pixels x (gin, y) of this lane's channel group, up to three (pixel, tap) pairs
+    // (a second set in flight cost a resident workgroup per CU in registers and was slower: 46 vs 38 us at batch 512)
+    struct InFlight {
+        uint4 g[2], y[2];
+        uint2 x[3];
+    };
+    InFlight r0;
+    auto fetch = [&](InFlight& r, int tile) {
+        uint4(&rg)[2] = r.g;
+        uint4(&ry)[2] = r.y;
+        uint2(&rx)[3] = r.x;
+        const int k0 = tile * C1_BK;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = k0 + pl + 32 * h;
+            rg[h] = ry[h] = make_uint4(0u, 0u, 0u, 0u);
+            if (k < p.npix) {
+                rg[h] = *(const uint4*)(p.gin + (long)k * 64 + c0);
+                ry[h] = *(const uint4*)(p.y + (long)k * 64 + c0);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int idx = tid + 256 * q;                  // (pixel, tap) pair: 64 x 9 = 576 of them
+            rx[q] = make_uint2(0u, 0u);
+            if (idx < C1_BK * 9) {
+                const int px = idx / 9, tap = idx - px * 9;
+                const int k = k0 + px;
+                int h, w;
+                if (p.wshift >= 0 && p.hshift >= 0) { w = k & (p.W - 1); h = (k >> p.wshift) & (p.H - 1); }
+                else { w = k % p.W; h = (k / p.W) % p.H; }
+                const int dh = tap / 3 - 1, dw = tap - (tap / 3) * 3 - 1;
+                if (k < p.npix && (unsigned)(h + dh) < (unsigned)p.H && (unsigned)(w + dw) < (unsigned)p.W)
+                    rx[q] = *(const uint2*)(p.x8 + (long)(k + dh * p.W + dw) * 8);
+            }
+        }
+    };
+    // the fetched registers -> LDS stage `buf`: d = gin where the ReLU passed (the forward's fp32 predicate), y as it is
+    auto deposit = [&](const InFlight& r, int buf) {
+        const uint4(&rg)[2] = r.g;
+        const uint4(&ry)[2] = r.y;
+        const uint2(&rx)[3] = r.x;
+        unsigned char* abase = smem + buf * C1_STAGE;
+        unsigned char* xbase = abase + C1_A_BYTES;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int row = pl + 32 * h;
+            const uint32_t gw[4] = {rg[h].x, rg[h].y, rg[h].z, rg[h].w}, yw[4] = {ry[h].x, ry[h].y, ry[h].z, ry[h].w};
+            uint32_t dwd[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint32_t keep = 0u;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int i = 2 * j + e;
+                    const float v = __uint_as_float(e ? (yw[j] & 0xFFFF0000u) : (yw[j] << 16));
+                    if (v * sc[i] + sh[i] > 0.f) keep |= e ? 0xFFFF0000u : 0x0000FFFFu;
+                }
+                dwd[j] = gw[j] & keep;
+            }
+            const int s = c1_swz_a(row);
+            *(uint4*)(abase + row * C1_ROWA + ((cg ^ s) << 4)) = make_uint4(dwd[0], dwd[1], dwd[2], dwd[3]);
+            *(uint4*)(abase + row * C1_ROWA + (((8 + cg) ^ s) << 4)) = ry[h];
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int idx = tid + 256 * q;
+            if (idx < C1_BK * 9) {
+                const int px = idx / 9, tap = idx - px * 9;
+                const uint32_t xw[2] = {rx[q].x, rx[q].y};
+                for (int ci = 0; ci < p.Cin; ++ci) {
+                    const int off = (tap * p.Cin + ci) * 2;
+                    const bf16_t v = (bf16_t)((ci & 1) ? (xw[ci >> 1] >> 16) : (xw[ci >> 1] & 0xFFFFu));
+                    *(bf16_t*)(xbase + px * C1_ROWX + ((((off >> 4) ^ c1_swz_x(px)) << 4) | (off & 15))) = v;
+                }
+            }
+        }
+    };
+
+    // wave w: T rows of d channels 16 w .. 16 w + 15 (acc[.][0]) and of y channels 16 w .. (acc[.][1]); accd = d^T y of
+    // those two blocks, whose diagonal is sum_p d * y; wave 0 also the all-ones row
+    f32x4 acc[2][2], acc1[2], accd = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        acc1[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    // all-ones operand: channel (lane & 15) == 0 of its block is 1.0 for every k, the rest 0
+    typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+    const unsigned short one = (lane & 15) == 0 ? (unsigned short)0x3F80 : (unsigned short)0;
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, (u16x8){one, one, one, one, one, one, one, one});
+
+    // the matrix work of the tile in stage `buf`: one half of K at a time (fewer live fragments)
+    auto compute = [&](int buf) {
+        const unsigned abase = (unsigned)(size_t)(lptr_t)smem + (unsigned)(buf * C1_STAGE), xbase = abase + C1_A_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 xa[2], cb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                xa[i] = c1_frag<true>(xbase, kk * 32, i * 16, lane);
+                cb[i] = c1_frag<false>(abase, kk * 32, i * 64 + wave * 16, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { c1_wait(xa[i]); c1_wait(cb[i]); }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[i], cb[j], acc[i][j], 0, 0, 0);
+                if (wave == 0) acc1[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[i], ones, acc1[i], 0, 0, 0);
+            }
+            accd = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cb[0], cb[1], accd, 0, 0, 0);
+        }
+    };
+
+    const int G = gridDim.x;
+    int tile = blockIdx.x;
+    fetch(r0, tile);
+    __syncthreads();                       // the clear and the ones column are complete
+    deposit(r0, 0);
+    barrier_keep_copies();
+    int buf = 0;
+    for (; tile < p.ntile; tile += G) {
+        const bool more = tile + G < p.ntile;
+        if (more) fetch(r0, tile + G);
+        compute(buf);
+        if (more) deposit(r0, buf ^ 1);
+        barrier_keep_copies();             // stage buf is read out, stage buf ^ 1 is written
+        buf ^= 1;
+    }
+
+    // acc[i][j][r]: column 16 i + 4 (lane >> 4) + r of T row 64 j + 16 wave + (lane & 15)
+    float* out = p.part + (long)blockIdx.x * C1_ROWF;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int col = 16 * i + 4 * (lane >> 4);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            *(float4*)(out + (64 * j + 16 * wave + (lane & 15)) * C1_COLS + col) =
+                make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        if (wave == 0 && (lane & 15) == 0)
+            *(float4*)(out + 128 * C1_COLS + col) = make_float4(acc1[i][0], acc1[i][1], acc1[i][2], acc1[i][3]);
+    }
+    // accd[r]: d channel 4 (lane >> 4) + r against y channel (lane & 15) of the wave's block: keep the diagonal
+    const int r = (lane & 15) - 4 * (lane >> 4);
+    if (r >= 0 && r < 4)
+        out[C1_TROWS * C1_COLS + 16 * wave + (lane & 15)] = r == 0 ? accd[0] : r == 1 ? accd[1] : r == 2 ? accd[2] : accd[3];
+}
+
+// folded [C1_ROWF] -> dW [64][Cin][9], sums = [d gamma (64) | d beta (64)]
+__global__ __launch_bounds__(256) void bn_bwd_conv1_combine_kernel(const float* __restrict__ folded,
+                                                                   const float* __restrict__ scale,
+                                                                   const float* __restrict__ mean,
+                                                                   const float* __restrict__ rstd, double inv_count,
+                                                                   float* __restrict__ sums, float* __restrict__ dW, int Cin) {
+    const float* st = folded + C1_TROWS * C1_COLS;          // sum d * y; sum d = T1[c][31]
+    for (int o = threadIdx.x; o < 64 * 9 * Cin; o += 256) {
+        const int co = o / (9 * Cin), rem = o - co * 9 * Cin;
+        const int ci = rem / 9, tap = rem - ci * 9;
+        const int col = tap * Cin + ci;
+        const double t1 = folded[co * C1_COLS + col], ty = folded[(64 + co) * C1_COLS + col], t2 = folded[128 * C1_COLS + col];
+        const double t3 = (double)rstd[co] * (ty - (double)mean[co] * t2);
+        const double s_d = folded[co * C1_COLS + 31];
+        const double s_dx = (double)rstd[co] * ((double)st[co] - (double)mean[co] * s_d);      // sum d * xhat
+        const double m_dx = s_dx * inv_count, m_d = s_d * inv_count;
+        dW[o] = (float)((double)scale[co] * (t1 - m_d * t2 - m_dx * t3));
+    }
+    if (threadIdx.x < 64) {
+        const int c = threadIdx.x;
+        const double s_d = folded[c * C1_COLS + 31];
+        sums[c] = (float)((double)rstd[c] * ((double)st[c] - (double)mean[c] * s_d));
+        sums[64 + c] = (float)s_d;
+    }
+}
+
+static int c1_blocks(long npix) {
+    const long nt = (npix + C1_BK - 1) / C1_BK;
+    return (int)(nt < C1_MAX_BLOCKS ? nt : C1_MAX_BLOCKS);
+}
+static int c1_shift(int v) {
+    if (v <= 0 || (v & (v - 1))) return -1;
+    int s = 0;
+    while ((1 << s) < v) ++s;
+    return s;
+}
+
+}  // namespace vae
+
+using namespace vae;
+
+extern "C" long vae_bn_bwd_conv1_scratch_floats(int n_img, int H, int W) {
+    if (n_img <= 0 || H <= 0 || W <= 0) return -1;
+    return ((long)c1_blocks((long)n_img * H * W) + 1) * C1_ROWF;
+}
+
+extern "C" int vae_bn_bwd_conv1(const void* gin, const void* y, const void* x8, const float* scale, const float* shift,
+                                const float* mean, const float* rstd, float* scratch, float* sums, float* dW, int n_img,
+                                int H, int W, int Cin, void* stream) {
+    VAE_CHECK(gin && y && x8 && scale && shift && mean && rstd && scratch && sums && dW, "vae_bn_bwd_conv1: null pointer");
+    VAE_CHECK(n_img > 0 && H > 0 && W > 0 && (long)n_img * H * W < (1L << 31) - 64 * C1_MAX_BLOCKS,
+              "vae_bn_bwd_conv1: bad geometry n=%d H=%d W=%d", n_img, H, W);
+    VAE_CHECK(Cin >= 1 && Cin <= 3, "vae_bn_bwd_conv1: Cin=%d out of range (1..3: nine taps of Cin channels must fit 32 columns)", Cin);
+    VAE_CHECK((((uintptr_t)gin | (uintptr_t)y | (uintptr_t)scratch) & 15) == 0 && ((uintptr_t)x8 & 7) == 0,
+              "vae_bn_bwd_conv1: gin, y and scratch must be 16-byte aligned, x8 8-byte aligned");
+    const long npix = (long)n_img * H * W;
+    Conv1Bwd p = {};
+    p.gin = (const bf16_t*)gin; p.y = (const bf16_t*)y; p.x8 = (const bf16_t*)x8;
+    p.scale = scale; p.shift = shift; p.mean = mean; p.rstd = rstd; p.part = scratch;
+    p.npix = (int)npix; p.H = H; p.W = W; p.wshift = c1_shift(W); p.hshift = c1_shift(H); p.Cin = Cin;
+    p.ntile = (int)((npix + C1_BK - 1) / C1_BK);
+    const int nb = c1_blocks(npix);
+    hipStream_t s = (hipStream_t)stream;
+    {
+        // gin and y read once, the 8-channel input once
+        ProfScope prof("bn_bwd_conv1_kernel", 0.0, (double)npix * (2.0 * 64 * 2 + 16), s);
+        hipLaunchKernelGGL(bn_bwd_conv1_kernel, dim3(nb), dim3(256), 0, s, p);
+        VAE_LAUNCH_CHECK("bn_bwd_conv1_kernel");
+    }
+    float* folded = scratch + (long)nb * C1_ROWF;
+    if (int e = vae_sum_partials(scratch, nb, C1_ROWF, folded, 1.0f, stream)) return e;
+    hipLaunchKernelGGL(bn_bwd_conv1_combine_kernel, dim3(1), dim3(256), 0, s, folded, scale, mean, rstd, 1.0 / (double)npix,
+                       sums, dW, Cin);
+    VAE_LAUNCH_CHECK("bn_bwd_conv1_combine_kernel");
+    return 0;
+}

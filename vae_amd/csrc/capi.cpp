@@ -63,6 +63,7 @@ extern int g_conv3_ksplit_mode;
 extern int g_stream_gemm_mode;
 extern int g_wgrad_pc_mode;
 extern int g_conv3_ws64_mode;
+extern int g_conv1_bwd_mode;
 extern unsigned long long* g_conv3_dbg;
 }
 // Diagnostic aid: a device buffer that diagnostic kernel variants write cycle stamps to (null = none).
@@ -86,6 +87,10 @@ extern "C" int vae_set_tuning(const char* key, int value) {
     }
     if (key && !strcmp(key, "conv3_ws64")) {          // weight-stationary conv3x3 for 64 input channels: 0 where its jobs fill the chip, 1 never, 2 wherever legal
         vae::g_conv3_ws64_mode = value;
+        return 0;
+    }
+    if (key && !strcmp(key, "conv1_bwd")) {           // first conv's BatchNorm backward + weight gradient: 0 the one-pass kernel where Cin <= 3, 1 separate passes
+        vae::g_conv1_bwd_mode = value;
         return 0;
     }
     if (key && !strcmp(key, "stream_gemm")) {         // 0 the streaming GEMM where it pays, 1 never (tiled GEMM), 2 wherever legal

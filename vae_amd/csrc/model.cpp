@@ -15,6 +15,8 @@
 
 #include "model_layout.h"
 
+namespace vae { extern int g_conv1_bwd_mode; }
+
 namespace {
 using namespace vae_model;
 
@@ -65,6 +67,9 @@ struct WsLayout {
     long total_bytes;
 };
 
+// the first conv's BatchNorm backward and weight gradient as one kernel (it holds nine taps x Cin columns in 32)
+static bool conv1_one_pass(const Dims& d) { return vae::g_conv1_bwd_mode == 0 && d.Cin <= 3; }
+
 long enc_elems(const Dims& d, int b) { const long h = d.S >> b; return (long)d.N * h * h * ENC_C[b]; }
 
 int rows_blocks(long M) { return (int)((M + vae_gemm_rows_per_block() - 1) / vae_gemm_rows_per_block()); }
@@ -104,6 +109,7 @@ void make_ws_layout(const Dims& d, WsLayout* w) {
     // the buffer holds all of them side by side (a few hundred MB of 288 GB)
     auto up64 = [](long v) { return (v + 63) / 64 * 64; };
     long s = up64(slab_need(64, 64, 2, npix));
+    if (d.Cin <= 3) { const long v = up64(vae_bn_bwd_conv1_scratch_floats(d.N, d.S, d.S)); if (v > s) s = v; }   // either form of the first conv's backward
     for (int i = 0; i < 7; ++i) {
         const int b = (i + 1) / 2;     // encoder block of conv i (c1b -> 0, c2a,c2b -> 1, ...)
         const long h = d.S >> b;
@@ -598,6 +604,15 @@ static int backward_block(const Ctx& c, Fork* f, int b, const void* const* masks
     TRY(vae_conv3x3_gemm(c.at(w.g[ib]), c.pk_at(c.pk.conv_d[2 * b]), nullptr, c.at(w.g[ic]), nullptr, nullptr, d.N, H, H, C, C,
                          c.stream));
     // first conv + BN + ReLU: c -> a
+    if (b == 0 && conv1_one_pass(d)) {
+        // nothing needs the first conv's input gradient: BatchNorm backward and weight gradient in one pass, no tensor written
+        float* scratch = nullptr;
+        TRY(slab_take(c, f, vae_bn_bwd_conv1_scratch_floats(d.N, H, H), &scratch));
+        TRY(vae_bn_bwd_conv1(c.at(w.g[ic]), c.at(w.ya[0]), c.at(w.x8), c.coef(0, 0), c.coef(0, 1), c.coef(0, 2), c.coef(0, 3),
+                             scratch, c.G(2), c.G(0), d.N, H, H, d.Cin, c.stream));
+        TRY(side_after_main(f));           // the stage's fold launch follows it: the scratch rows sit in the slab buffer
+        return side_mark(f, w_carry);
+    }
     TRY(vae_bn_act_bwd(c.at(w.g[ic]), c.at(w.ya[b]), c.coef(2 * b, 0), c.coef(2 * b, 1), c.coef(2 * b, 2), c.coef(2 * b, 3),
                        (float*)c.at(w.bnpart), c.G(8 * b + 2), c.at(w.g[ia]), d.N, H, H, C, 0, 0.0, nullptr, 0, 0, 0, 0, c.stream));
     TRY(side_after_main(f));
