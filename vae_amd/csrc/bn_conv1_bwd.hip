@@ -69,6 +69,7 @@ __device__ __forceinline__ bf16x8 c1_frag(unsigned base, int k0, int col0, int l
 }
 __device__ __forceinline__ void c1_wait(bf16x8& f) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f) : : "memory"); }
 
+template <int CIN>
 __global__ __launch_bounds__(256, 3) void bn_bwd_conv1_kernel(const Conv1Bwd p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * C1_STAGE];
     typedef __attribute__((address_space(3))) void* lptr_t;
@@ -160,8 +161,9 @@ __global__ __launch_bounds__(256, 3) void bn_bwd_conv1_kernel(const Conv1Bwd p) 
             if (idx < C1_BK * 9) {
                 const int px = idx / 9, tap = idx - px * 9;
                 const uint32_t xw[2] = {rx[q].x, rx[q].y};
-                for (int ci = 0; ci < p.Cin; ++ci) {
-                    const int off = (tap * p.Cin + ci) * 2;
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) {
+                    const int off = (tap * CIN + ci) * 2;
                     const bf16_t v = (bf16_t)((ci & 1) ? (xw[ci >> 1] >> 16) : (xw[ci >> 1] & 0xFFFFu));
                     *(bf16_t*)(xbase + px * C1_ROWX + ((((off >> 4) ^ c1_swz_x(px)) << 4) | (off & 15))) = v;
                 }
@@ -307,7 +309,9 @@ extern "C" int vae_bn_bwd_conv1(const void* gin, const void* y, const void* x8, 
     {
         // gin and y read once, the 8-channel input once
         ProfScope prof("bn_bwd_conv1_kernel", 0.0, (double)npix * (2.0 * 64 * 2 + 16), s);
-        hipLaunchKernelGGL(bn_bwd_conv1_kernel, dim3(nb), dim3(256), 0, s, p);
+        if (Cin == 1) hipLaunchKernelGGL(bn_bwd_conv1_kernel<1>, dim3(nb), dim3(256), 0, s, p);
+        else if (Cin == 2) hipLaunchKernelGGL(bn_bwd_conv1_kernel<2>, dim3(nb), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(bn_bwd_conv1_kernel<3>, dim3(nb), dim3(256), 0, s, p);
         VAE_LAUNCH_CHECK("bn_bwd_conv1_kernel");
     }
     float* folded = scratch + (long)nb * C1_ROWF;
