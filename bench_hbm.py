@@ -88,6 +88,15 @@ def main():
         "vae_bn_act_bwd_route", gp.data_ptr(), y.data_ptr(), sc.data_ptr(), sh.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
         partp.data_ptr(), sums.data_ptr(), dy.data_ptr(), route.data_ptr(), N, H, H, C, 1, 0.1, None, 1337, 0, 0, 0, s()))
 
+    # ---- first conv's BatchNorm backward + weight gradient in one pass: gin, y and the 8-channel input read once
+    x8 = torch.rand(N, H, H, 8, device=dev).to(torch.bfloat16)
+    scratch = torch.empty(L.call("vae_bn_bwd_conv1_scratch_floats", N, H, H), device=dev)
+    dw = torch.empty(64 * 27, device=dev)
+    add("bn_bwd_conv1 (BatchNorm backward + conv weight gradient, one pass)", N * H * H * (2.0 * 2 * C + 16.0), lambda: L.call(
+        "vae_bn_bwd_conv1", g.data_ptr(), y.data_ptr(), x8.data_ptr(), sc.data_ptr(), sh.data_ptr(), mean.data_ptr(),
+        rstd.data_ptr(), scratch.data_ptr(), sums.data_ptr(), dw.data_ptr(), N, H, H, 3, s()))
+    del x8, scratch
+
     # ---- GroupNorm(8) + ReLU (+ dropout + pool): one workgroup per image; algorithmic bytes count y ONCE per pass
     # (the second read of an image comes from L2), gin and the output once
     mr = torch.empty(N, 8, 2, device=dev)
