@@ -61,7 +61,9 @@ int vae_prof_stop(char* names, int* launches, double* total_ms, double* flops, d
  * 0 the conv3x3 weight gradient with separate copying and computing waves for long K ranges (default), 1 always, 2 never; "conv3_ws64" =
  * 0 the weight-stationary conv3x3 kernel for launches with 64 input channels whose tiles fill the chip (default), 1 never, 2 wherever
  * its geometry allows (16- or 32-wide images, whole 256-pixel tiles), 3 as 0 with a hand-pipelined K loop (faster alone, not in the step on every box); "conv1_bwd" = 0 the whole-model backward runs
- * the first conv's BatchNorm backward and weight gradient as vae_bn_bwd_conv1 where Cin <= 3 (default), 1 as separate passes.  Not thread-safe: set it while nothing is being
+ * the first conv's BatchNorm backward and weight gradient as vae_bn_bwd_conv1 where Cin <= 3 (default), 1 as separate passes;
+ * "pool_ymax" = 0 the whole-model passes keep the conv output at each pooling window's maximum for the backward sums (default), 1 they
+ * re-read the windows.  Not thread-safe: set it while nothing is being
  * launched. */
 int vae_set_tuning(const char* key, int value);
 /* Diagnostic aid: device buffer (>= 128 bytes per workgroup of the launch under study) that the diagnostic kernel
@@ -258,6 +260,13 @@ int vae_bn_act_fwd_route(const void* y, const float* scale, const float* shift, 
                          int n_img, int H, int W, int C, int pool, double p_drop, const void* keep_mask,
                          unsigned long long seed, unsigned step, unsigned stream_id, unsigned rank,
                          void* stream);
+/* The same, also leaving ymax [n,H/2,W/2,C] bf16: the conv output y at each window's maximum (null: not written; it needs
+ * route).  vae_bn_act_bwd_route_y then reduces its per-channel sums from ymax instead of re-reading the four window
+ * elements of y: a quarter of that pass's reads of y, bit-identical sums (the values are the same bf16 numbers). */
+int vae_bn_act_fwd_route_y(const void* y, const float* scale, const float* shift, void* out, void* route, void* ymax,
+                           int n_img, int H, int W, int C, int pool, double p_drop, const void* keep_mask,
+                           unsigned long long seed, unsigned step, unsigned stream_id, unsigned rank,
+                           void* stream);
 /* rows of the `partial` workspace (x 2*C floats) used by vae_bn_act_bwd */
 int vae_bn_act_bwd_blocks(int n_img, int H, int W, int C, int pool);
 /* backward of the above down to the conv output: gin = grad of the (pooled) block output,
@@ -274,6 +283,12 @@ int vae_bn_act_bwd_route(const void* gin, const void* y, const float* scale, con
                          const void* route, int n_img, int H, int W, int C, int pool, double p_drop,
                          const void* keep_mask, unsigned long long seed, unsigned step,
                          unsigned stream_id, unsigned rank, void* stream);
+/* vae_bn_act_bwd_route with the ymax tensor vae_bn_act_fwd_route_y left (null: as vae_bn_act_bwd_route). */
+int vae_bn_act_bwd_route_y(const void* gin, const void* y, const float* scale, const float* shift,
+                           const float* mean, const float* rstd, float* partial, float* sums, void* dy,
+                           const void* route, const void* ymax, int n_img, int H, int W, int C, int pool,
+                           double p_drop, const void* keep_mask, unsigned long long seed, unsigned step,
+                           unsigned stream_id, unsigned rank, void* stream);
 /* Backward of the network's first  Conv2d(Cin, 64, 3, padding=1) -> BatchNorm2d(64) -> ReLU  (vae/models/vae.py:24-31
  * with in_channels = the image channels, vae.py:34) in one pass over gin and y.  Nothing in front of that conv takes
  * an input gradient, so the gradient of the conv output is never stored: the kernel accumulates per channel

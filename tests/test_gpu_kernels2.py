@@ -267,6 +267,25 @@ def test_bn_act_fwd_bwd(L, n, H, W, C, pool, p, inject):
     assert rel_l2(sums2[C:].cpu(), br.grad) <= 2e-5
     check_bf16(from_nhwc(dy2), yr.grad, "bn_act bwd (routed)", rtol=4e-3)
     assert rel_l2(dy2.float().cpu(), dy.float().cpu()) <= 3e-3      # same result as the recomputing form, to bf16 rounding
+    # ---- the same pair with ymax: the forward also leaves the conv output at each window's maximum, the backward's
+    # reduction reads that instead of the four window elements -- the same numbers, so bit-identical results
+    ymax = torch.full((n, H // 2, W // 2, C), float("nan"), device=DEV, dtype=torch.bfloat16)
+    route3 = torch.full_like(route, 255)
+    out3 = torch.full_like(out, float("nan"))
+    L.call("vae_bn_act_fwd_route_y", L.ptr(yd), L.ptr(sc), L.ptr(sh), L.ptr(out3), L.ptr(route3), L.ptr(ymax), n, H, W, C, pool,
+           p, L.ptr(md), seed, step, stream_id, rank, L.current_stream())
+    assert torch.equal(out3, out) and torch.equal(route3, route)
+    ywin = yd.view(n, H // 2, 2, W // 2, 2, C).permute(0, 1, 3, 5, 2, 4).reshape(n, H // 2, W // 2, C, 4)
+    assert torch.equal(ymax, torch.gather(ywin, 4, (route & 3).long().unsqueeze(-1)).squeeze(-1))
+    partial.fill_(float("nan")); sums3 = torch.full_like(sums, float("nan")); dy3 = torch.full_like(dy, float("nan"))
+    L.call("vae_bn_act_bwd_route_y", L.ptr(gind), L.ptr(yd), L.ptr(sc), L.ptr(sh), L.ptr(mean), L.ptr(rstd), L.ptr(partial),
+           L.ptr(sums3), L.ptr(dy3), L.ptr(route), L.ptr(ymax), n, H, W, C, pool, p, L.ptr(md), seed, step, stream_id, rank,
+           L.current_stream())
+    assert torch.equal(sums3, sums2) and torch.equal(dy3, dy2)
+    with pytest.raises(RuntimeError, match="ymax goes with the route bytes"):
+        L.call("vae_bn_act_bwd_route_y", L.ptr(gind), L.ptr(yd), L.ptr(sc), L.ptr(sh), L.ptr(mean), L.ptr(rstd), L.ptr(partial),
+               L.ptr(sums3), L.ptr(dy3), None, L.ptr(ymax), n, H, W, C, pool, p, L.ptr(md), seed, step, stream_id, rank,
+               L.current_stream())
 
 
 def test_bn_finalize_eval_and_fold(L):

@@ -62,6 +62,10 @@ SIGNATURES = {
                                     c_uint, c_uint, c_uint, P]),
     "vae_bn_act_bwd_route": (None, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_double, P,
                                     c_ulonglong, c_uint, c_uint, c_uint, P]),
+    "vae_bn_act_fwd_route_y": (None, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_double, P, c_ulonglong,
+                                      c_uint, c_uint, c_uint, P]),
+    "vae_bn_act_bwd_route_y": (None, [P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_double, P,
+                                      c_ulonglong, c_uint, c_uint, c_uint, P]),
     "vae_bn_act_bwd_blocks": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "vae_bn_bwd_conv1_scratch_floats": (c_long, [c_int, c_int, c_int]),
     "vae_bn_bwd_conv1": (None, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),

@@ -64,6 +64,7 @@ extern int g_stream_gemm_mode;
 extern int g_wgrad_pc_mode;
 extern int g_conv3_ws64_mode;
 extern int g_conv1_bwd_mode;
+extern int g_pool_ymax_mode;
 extern unsigned long long* g_conv3_dbg;
 }
 // Diagnostic aid: a device buffer that diagnostic kernel variants write cycle stamps to (null = none).
@@ -91,6 +92,10 @@ extern "C" int vae_set_tuning(const char* key, int value) {
     }
     if (key && !strcmp(key, "conv1_bwd")) {           // first conv's BatchNorm backward + weight gradient: 0 the one-pass kernel where Cin <= 3, 1 separate passes
         vae::g_conv1_bwd_mode = value;
+        return 0;
+    }
+    if (key && !strcmp(key, "pool_ymax")) {           // pooled BatchNorm backward sums from the stored window maxima: 0 yes, 1 re-read the windows
+        vae::g_pool_ymax_mode = value;
         return 0;
     }
     if (key && !strcmp(key, "stream_gemm")) {         // 0 the streaming GEMM where it pays, 1 never (tiled GEMM), 2 wherever legal

@@ -15,7 +15,7 @@
 
 #include "model_layout.h"
 
-namespace vae { extern int g_conv1_bwd_mode; }
+namespace vae { extern int g_conv1_bwd_mode; extern int g_pool_ymax_mode; }
 
 namespace {
 using namespace vae_model;
@@ -63,6 +63,7 @@ struct WsLayout {
     long slab_floats;
     long g[3];              // gradient ping-pong buffers (three: a weight-gradient kernel may still read one)
     long route[3];          // pooled blocks: one byte per pooled element, which window element won and whether it is live
+    long ymax[3];           // pooled blocks: the conv output at each window's maximum (bf16), for the backward sums
     long slab2, slab2_floats;
     long total_bytes;
 };
@@ -85,7 +86,7 @@ void make_ws_layout(const Dims& d, WsLayout* w) {
         const long e = enc_elems(d, b);
         w->ya[b] = put(e * 2); w->aa[b] = put(e * 2); w->yb[b] = put(e * 2);
         w->ob[b] = put((b < 3 ? e / 4 : e) * 2);
-        if (b < 3) w->route[b] = put(e / 4);
+        if (b < 3) { w->route[b] = put(e / 4); w->ymax[b] = put(e / 4 * 2); }
     }
     w->coef = put(11L * 4 * 256 * 4);
     const long stat = (long)rows_blocks(npix) * 64;       // widest: first block (64 ch at full res) == up1 (256 cols at half res)
@@ -324,8 +325,9 @@ static int encoder_forward(const Ctx& c, const float* x, const void* const* mask
         TRY(vae_conv3x3_gemm(c.at(w.aa[b]), c.pk_at(c.pk.conv_f[2 * b]), c.P(8 * b + 5), c.at(w.yb[b]), ss, sq, d.N, H, H, C,
                              C, c.stream));
         TRY(bn_finalize(c, 2 * b + 1, 8 * b + 6, rows, 1, (double)M));
-        TRY(vae_bn_act_fwd_route(c.at(w.yb[b]), c.coef(2 * b + 1, 0), c.coef(2 * b + 1, 1), c.at(w.ob[b]),
-                                 train && b < 3 ? c.at(w.route[b]) : nullptr, d.N, H, H, C, b < 3, p,
+        TRY(vae_bn_act_fwd_route_y(c.at(w.yb[b]), c.coef(2 * b + 1, 0), c.coef(2 * b + 1, 1), c.at(w.ob[b]),
+                                 train && b < 3 ? c.at(w.route[b]) : nullptr, train && b < 3 && vae::g_pool_ymax_mode == 0 ? c.at(w.ymax[b]) : nullptr,
+                                 d.N, H, H, C, b < 3, p,
                                  masks ? masks[b] : nullptr, c.cfg->seed, c.cfg->step, VAE_STREAM_DROPOUT0 + b, c.cfg->rank,
                                  c.stream));
         in = c.at(w.ob[b]);
@@ -589,9 +591,10 @@ static int backward_block(const Ctx& c, Fork* f, int b, const void* const* masks
     int ns = 1;
     const double p = c.cfg->p_dropout;
     // second conv + BN + ReLU + dropout (+ pool): a -> b
-    TRY(vae_bn_act_bwd_route(c.at(w.g[ia]), c.at(w.yb[b]), c.coef(2 * b + 1, 0), c.coef(2 * b + 1, 1), c.coef(2 * b + 1, 2),
+    TRY(vae_bn_act_bwd_route_y(c.at(w.g[ia]), c.at(w.yb[b]), c.coef(2 * b + 1, 0), c.coef(2 * b + 1, 1), c.coef(2 * b + 1, 2),
                              c.coef(2 * b + 1, 3), (float*)c.at(w.bnpart), c.G(8 * b + 6), c.at(w.g[ib]),
-                             b < 3 ? c.at(w.route[b]) : nullptr, d.N, H, H, C, b < 3, p, masks ? masks[b] : nullptr,
+                             b < 3 ? c.at(w.route[b]) : nullptr, b < 3 && vae::g_pool_ymax_mode == 0 ? c.at(w.ymax[b]) : nullptr, d.N, H, H, C, b < 3, p,
+                             masks ? masks[b] : nullptr,
                              c.cfg->seed, c.cfg->step, VAE_STREAM_DROPOUT0 + b, c.cfg->rank, c.stream));
     TRY(side_after_main(f));
     float* slab = nullptr;

@@ -143,6 +143,8 @@ __global__ __launch_bounds__(1024) void sum_partials_kernel(const float* __restr
 }
 
 // ---------------------------------------------------------------------------------------
+int g_pool_ymax_mode = 0;
+
 static int pow2_shift(int v) {
     if (v <= 0 || (v & (v - 1))) return -1;
     int s = 0;
@@ -177,7 +179,8 @@ __device__ __forceinline__ void split_pooled(const ActGeom& g, unsigned pos, int
 template <bool POOL>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16_t* __restrict__ y, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, bf16_t* __restrict__ out,
-                                                         uint8_t* __restrict__ route, ActGeom g, DropCfg d) {
+                                                         uint8_t* __restrict__ route, bf16_t* __restrict__ ymax, ActGeom g,
+                                                         DropCfg d) {
     const int cgs = g.C >> 3;
     const long npos = POOL ? (long)g.n_img * (g.H >> 1) * (g.W >> 1) : (long)g.n_img * g.H * g.W;
     // cgs is a power of two dividing 256: a thread keeps its channel group, positions advance by a fixed stride
@@ -199,6 +202,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16_t* __restric
             long img;
             split_pooled(g, pos, wo, ho, img);
             uint32_t arg[8];
+            float ys[8];                       // the conv output at the window's maximum
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const long pix = (img * g.H + 2 * ho + (k >> 1)) * g.W + 2 * wo + (k & 1);
@@ -207,10 +211,11 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16_t* __restric
                 act8(v, sc, sh, d, pix * g.C + c0, a, ps, kp);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    if (k == 0) { o[i] = a[i]; arg[i] = 0; }
-                    else if (a[i] > o[i]) { o[i] = a[i]; arg[i] = k; }       // strict >: the first maximum wins, as in MaxPool2d
+                    if (k == 0) { o[i] = a[i]; arg[i] = 0; ys[i] = v[i]; }
+                    else if (a[i] > o[i]) { o[i] = a[i]; arg[i] = k; ys[i] = v[i]; }       // strict >: the first maximum wins, as in MaxPool2d
                 }
             }
+            if (ymax) store8s(ymax + (long)pos * g.C + c0, ys);      // exact: the values are bf16 already
             if (route) {
                 uint32_t r[8];
 #pragma unroll
@@ -231,7 +236,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const bf16_t* __restric
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          const float* __restrict__ sums, float inv_count,
                                                          float* __restrict__ partial, bf16_t* __restrict__ dy,
-                                                         const uint8_t* __restrict__ route, ActGeom g, DropCfg d) {
+                                                         const uint8_t* __restrict__ route, const bf16_t* __restrict__ ymax,
+                                                         ActGeom g, DropCfg d) {
     __shared__ float red[2][256][8];
     const int cgs = g.C >> 3;
     const long npos = POOL ? (long)g.n_img * (g.H >> 1) * (g.W >> 1) : (long)g.n_img * g.H * g.W;
@@ -280,6 +286,20 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const bf16_t* __restric
             long img;
             split_pooled(g, up, wo, ho, img);
             const uint2 rr = *(const uint2*)(route + pos * g.C + c0);
+            if (PASS == 0 && ymax) {
+                // the forward pass left the conv output at each window's maximum: a quarter of the reads, the same values
+                float vs[8];
+                load8(ymax + pos * g.C + c0, vs);
+                const float ik0 = d.enabled ? d.inv_keep : 1.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const uint32_t r = ((i < 4 ? rr.x : rr.y) >> (8 * (i & 3))) & 0xFFu;
+                    const float gg = (r & 4u) ? gi[i] * ik0 : 0.f;
+                    a_gx[i] += gg * ((vs[i] - mu[i]) * rs[i]);
+                    a_g[i] += gg;
+                }
+                continue;
+            }
             float v[4][8];
             long pix[4];
 #pragma unroll
@@ -640,6 +660,16 @@ extern "C" int vae_bn_act_fwd_route(const void* y, const float* scale, const flo
                                     int n_img, int H, int W, int C, int pool, double p_drop, const void* keep_mask,
                                     unsigned long long seed, unsigned step, unsigned stream_id, unsigned rank,
                                     void* stream) {
+    return vae_bn_act_fwd_route_y(y, scale, shift, out, route, nullptr, n_img, H, W, C, pool, p_drop, keep_mask, seed, step,
+                                  stream_id, rank, stream);
+}
+
+extern "C" int vae_bn_act_fwd_route_y(const void* y, const float* scale, const float* shift, void* out, void* route,
+                                      void* ymax, int n_img, int H, int W, int C, int pool, double p_drop,
+                                      const void* keep_mask, unsigned long long seed, unsigned step, unsigned stream_id,
+                                      unsigned rank, void* stream) {
+    VAE_CHECK(!ymax || route, "vae_bn_act_fwd_route_y: ymax goes with the route bytes");
+    VAE_CHECK(((uintptr_t)ymax & 15) == 0, "vae_bn_act_fwd_route_y: ymax must be 16-byte aligned");
     VAE_CHECK(y && scale && shift && out, "vae_bn_act_fwd: null pointer");
     VAE_CHECK(!route || pool, "vae_bn_act_fwd_route: route bytes exist only for the pooled form");
     VAE_CHECK(((uintptr_t)route & 7) == 0, "vae_bn_act_fwd_route: route must be 8-byte aligned");
@@ -650,9 +680,9 @@ extern "C" int vae_bn_act_fwd_route(const void* y, const float* scale, const flo
     const long items = (long)n_img * H * W / (pool ? 4 : 1) * (C / 8);
     hipStream_t s = (hipStream_t)stream;
     const double elems = (double)n_img * H * W * C;
-    ProfScope prof(pool ? "bn_act_fwd_kernel<pool>" : "bn_act_fwd_kernel", 0.0, 2.0 * elems * (pool ? 1.25 : 2.0), s);
-    if (pool) hipLaunchKernelGGL(bn_act_fwd_kernel<true>, dim3(elem_grid(items)), dim3(256), 0, s, (const bf16_t*)y, scale, shift, (bf16_t*)out, (uint8_t*)route, g, d);
-    else hipLaunchKernelGGL(bn_act_fwd_kernel<false>, dim3(elem_grid(items)), dim3(256), 0, s, (const bf16_t*)y, scale, shift, (bf16_t*)out, (uint8_t*)nullptr, g, d);
+    ProfScope prof(pool ? "bn_act_fwd_kernel<pool>" : "bn_act_fwd_kernel", 0.0, 2.0 * elems * (pool ? (ymax ? 1.5 : 1.25) : 2.0), s);
+    if (pool) hipLaunchKernelGGL(bn_act_fwd_kernel<true>, dim3(elem_grid(items)), dim3(256), 0, s, (const bf16_t*)y, scale, shift, (bf16_t*)out, (uint8_t*)route, (bf16_t*)ymax, g, d);
+    else hipLaunchKernelGGL(bn_act_fwd_kernel<false>, dim3(elem_grid(items)), dim3(256), 0, s, (const bf16_t*)y, scale, shift, (bf16_t*)out, (uint8_t*)nullptr, (bf16_t*)nullptr, g, d);
     VAE_LAUNCH_CHECK("bn_act_fwd_kernel");
     return 0;
 }
@@ -678,6 +708,18 @@ extern "C" int vae_bn_act_bwd_route(const void* gin, const void* y, const float*
                                     const void* route, int n_img, int H, int W, int C, int pool, double p_drop,
                                     const void* keep_mask, unsigned long long seed, unsigned step, unsigned stream_id,
                                     unsigned rank, void* stream) {
+    return vae_bn_act_bwd_route_y(gin, y, scale, shift, mean, rstd, partial, sums, dy, route, nullptr, n_img, H, W, C, pool,
+                                  p_drop, keep_mask, seed, step, stream_id, rank, stream);
+}
+
+extern "C" int vae_bn_act_bwd_route_y(const void* gin, const void* y, const float* scale, const float* shift,
+                                      const float* mean, const float* rstd, float* partial, float* sums, void* dy,
+                                      const void* route, const void* ymax, int n_img, int H, int W, int C, int pool,
+                                      double p_drop, const void* keep_mask, unsigned long long seed, unsigned step,
+                                      unsigned stream_id, unsigned rank, void* stream) {
+    VAE_CHECK(!ymax || route, "vae_bn_act_bwd_route_y: ymax goes with the route bytes");
+    VAE_CHECK(((uintptr_t)ymax & 15) == 0, "vae_bn_act_bwd_route_y: ymax must be 16-byte aligned");
+    const bf16_t* ym = (const bf16_t*)ymax;
     VAE_CHECK(gin && y && scale && shift && mean && rstd && partial && sums && dy, "vae_bn_act_bwd: null pointer");
     VAE_CHECK(!route || pool, "vae_bn_act_bwd_route: route bytes exist only for the pooled form");
     VAE_CHECK(((uintptr_t)route & 7) == 0, "vae_bn_act_bwd_route: route must be 8-byte aligned");
@@ -693,17 +735,17 @@ extern "C" int vae_bn_act_bwd_route(const void* gin, const void* y, const float*
     const double elems = (double)n_img * H * W * C;
     // both passes together: y read twice, gin read twice, dy written once
     ProfScope prof(pool ? "bn_act_bwd(reduce+apply)<pool>" : "bn_act_bwd(reduce+apply)", 0.0,
-                   2.0 * elems * (2.0 + 2.0 * (pool ? 0.25 : 1.0) + 1.0), s);
-    if (pool && rt) hipLaunchKernelGGL((bn_act_bwd_kernel<true, 0, true>), dim3(nb), dim3(256), 0, s, gi, yy, scale, shift, mean, rstd, sums, inv_count, partial, (bf16_t*)dy, rt, g, d);
-    else if (pool) hipLaunchKernelGGL((bn_act_bwd_kernel<true, 0, false>), dim3(nb), dim3(256), 0, s, gi, yy, scale, shift, mean, rstd, sums, inv_count, partial, (bf16_t*)dy, rt, g, d);
-    else hipLaunchKernelGGL((bn_act_bwd_kernel<false, 0, false>), dim3(nb), dim3(256), 0, s, gi, yy, scale, shift, mean, rstd, sums, inv_count, partial, (bf16_t*)dy, rt, g, d);
+                   2.0 * elems * ((ym ? 1.25 : 2.0) + 2.0 * (pool ? 0.25 : 1.0) + 1.0), s);
+    if (pool && rt) hipLaunchKernelGGL((bn_act_bwd_kernel<true, 0, true>), dim3(nb), dim3(256), 0, s, gi, yy, scale, shift, mean, rstd, sums, inv_count, partial, (bf16_t*)dy, rt, ym, g, d);
+    else if (pool) hipLaunchKernelGGL((bn_act_bwd_kernel<true, 0, false>), dim3(nb), dim3(256), 0, s, gi, yy, scale, shift, mean, rstd, sums, inv_count, partial, (bf16_t*)dy, rt, ym, g, d);
+    else hipLaunchKernelGGL((bn_act_bwd_kernel<false, 0, false>), dim3(nb), dim3(256), 0, s, gi, yy, scale, shift, mean, rstd, sums, inv_count, partial, (bf16_t*)dy, rt, ym, g, d);
     VAE_LAUNCH_CHECK("bn_act_bwd_kernel<0>");
     hipLaunchKernelGGL(sum_partials_kernel, dim3((2 * C + 31) / 32), dim3(1024), 0, s, partial, nb, 2 * C, 2 * C, sums, 1.0f);
     VAE_LAUNCH_CHECK("sum_partials_kernel");
     const int nb2 = elem_grid((long)n_img * H * W / (pool ? 4 : 1) * (C / 8));
-    if (pool && rt) hipLaunchKernelGGL((bn_act_bwd_kernel<true, 1, true>), dim3(nb2), dim3(256), 0, s, gi, yy, scale, shift, mean, rstd, sums, inv_count, partial, (bf16_t*)dy, rt, g, d);
-    else if (pool) hipLaunchKernelGGL((bn_act_bwd_kernel<true, 1, false>), dim3(nb2), dim3(256), 0, s, gi, yy, scale, shift, mean, rstd, sums, inv_count, partial, (bf16_t*)dy, rt, g, d);
-    else hipLaunchKernelGGL((bn_act_bwd_kernel<false, 1, false>), dim3(nb2), dim3(256), 0, s, gi, yy, scale, shift, mean, rstd, sums, inv_count, partial, (bf16_t*)dy, rt, g, d);
+    if (pool && rt) hipLaunchKernelGGL((bn_act_bwd_kernel<true, 1, true>), dim3(nb2), dim3(256), 0, s, gi, yy, scale, shift, mean, rstd, sums, inv_count, partial, (bf16_t*)dy, rt, ym, g, d);
+    else if (pool) hipLaunchKernelGGL((bn_act_bwd_kernel<true, 1, false>), dim3(nb2), dim3(256), 0, s, gi, yy, scale, shift, mean, rstd, sums, inv_count, partial, (bf16_t*)dy, rt, ym, g, d);
+    else hipLaunchKernelGGL((bn_act_bwd_kernel<false, 1, false>), dim3(nb2), dim3(256), 0, s, gi, yy, scale, shift, mean, rstd, sums, inv_count, partial, (bf16_t*)dy, rt, ym, g, d);
     VAE_LAUNCH_CHECK("bn_act_bwd_kernel<1>");
     return 0;
 }
