@@ -63,7 +63,7 @@ int vae_prof_stop(char* names, int* launches, double* total_ms, double* flops, d
  * its geometry allows (16- or 32-wide images, whole 256-pixel tiles), 3 as 0 with a hand-pipelined K loop (faster alone, not in the step on every box); "conv1_bwd" = 0 the whole-model backward runs
  * the first conv's BatchNorm backward and weight gradient as vae_bn_bwd_conv1 where Cin <= 3 (default), 1 as separate passes;
  * "pool_ymax" = 0 the whole-model passes keep the conv output at each pooling window's maximum for the backward sums (default), 1 they
- * re-read the windows.  Not thread-safe: set it while nothing is being
+ * re-read the windows; "head_sums" = 0 vae_head_bwd forms its per-channel sums on the matrix pipe (default), 1 in vector registers.  Not thread-safe: set it while nothing is being
  * launched. */
 int vae_set_tuning(const char* key, int value);
 /* Diagnostic aid: device buffer (>= 128 bytes per workgroup of the launch under study) that the diagnostic kernel
@@ -341,7 +341,7 @@ int vae_colsum_bf16(const void* x, long rows, int C, float* partial, float* out,
 int vae_head_fwd(const void* y, const float* scale, const float* shift, const float* w,
                  const float* b, float* recon, int n_img, int H, int W, int Cout, void* stream);
 int vae_head_bwd_blocks(int n_img, int H, int W);
-/* its backward: partial is blocks x (3+Cout)*64 floats of scratch; sums = [d gamma1(64) |
+/* its backward: partial is blocks x (3+Cout)*64 floats of scratch, 16-byte aligned; sums = [d gamma1(64) |
  * d beta1(64)]; sums_head = [dW[Cout][64] | db(Cout)] (Cout*65 floats);
  * dy [n,H,W,64] bf16 = grad of up1's output. */
 int vae_head_bwd(const float* drecon, const float* recon, const void* y, const float* scale,

@@ -42,6 +42,10 @@ struct Conv1Bwd {
     const float* rstd;
     float* part;
     int npix, H, W, wshift, hshift, Cin, ntile;
+    // head form (MODE 1): the loss gradient and the reconstruction, NCHW fp32 with hw pixels per plane
+    const float* drecon;
+    const float* recon;
+    int hw, hwshift;
 };
 
 // swizzles of the 16-byte chunk index: the 8 rows {b..b+3, b+8..b+11} one half of a transposing read touches land on
@@ -69,8 +73,15 @@ __device__ __forceinline__ bf16x8 c1_frag(unsigned base, int k0, int col0, int l
 }
 __device__ __forceinline__ void c1_wait(bf16x8& f) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f) : : "memory"); }
 
-template <int CIN>
+// MODE 0: the first conv (NC = input channels).  MODE 1: the sums of the 1x1 head's backward (NC = output channels), the
+// same contraction over pixels with other tiles: [pos * y | pos] (pos = 1.0 where the ReLU passed) against the logit
+// gradients dl[p][o] = drecon * recon * (1 - recon) split into two bf16 terms (columns o and 4 + o: products exact, the
+// split is good to 2^-17).  Everything the head's backward sums over pixels follows from P2[o][c] = sum_p dl (pos y) and
+// P1[o][c] = sum_p dl pos:  dW[o][c] = scale P2 + shift P1  (a = relu(scale y + shift)),  sum g = sum_o w[o][c] P1,
+// sum g y = sum_o w[o][c] P2  (g = pos * sum_o w[o][c] dl[o]),  db[o] = sum_p dl  (the all-ones row).
+template <int MODE, int NC>
 __global__ __launch_bounds__(256, 3) void bn_bwd_conv1_kernel(const Conv1Bwd p) {
+    constexpr int CIN = NC;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * C1_STAGE];
     typedef __attribute__((address_space(3))) void* lptr_t;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -96,6 +107,7 @@ __global__ __launch_bounds__(256, 3) void bn_bwd_conv1_kernel(const Conv1Bwd p) 
     struct InFlight {
         uint4 g[2], y[2];
         uint2 x[3];
+        float hr[4], hd[4];                 // MODE 1: recon and drecon of this lane's pixel (lanes 0..63)
     };
     InFlight r0;
     auto fetch = [&](InFlight& r, int tile) {
@@ -108,9 +120,25 @@ __global__ __launch_bounds__(256, 3) void bn_bwd_conv1_kernel(const Conv1Bwd p) 
             const int k = k0 + pl + 32 * h;
             rg[h] = ry[h] = make_uint4(0u, 0u, 0u, 0u);
             if (k < p.npix) {
-                rg[h] = *(const uint4*)(p.gin + (long)k * 64 + c0);
+                if (MODE == 0) rg[h] = *(const uint4*)(p.gin + (long)k * 64 + c0);
                 ry[h] = *(const uint4*)(p.y + (long)k * 64 + c0);
             }
+        }
+        if (MODE == 1) {
+#pragma unroll
+            for (int o = 0; o < 4; ++o) r.hr[o] = r.hd[o] = 0.f;
+            const int k = k0 + tid;
+            if (tid < C1_BK && k < p.npix) {
+                const unsigned up = (unsigned)k;
+                const unsigned img = p.hwshift >= 0 ? up >> p.hwshift : up / (unsigned)p.hw, pp = up - img * (unsigned)p.hw;
+#pragma unroll
+                for (int o = 0; o < NC; ++o) {
+                    const long e = ((long)img * NC + o) * p.hw + pp;
+                    r.hr[o] = p.recon[e];
+                    r.hd[o] = p.drecon[e];
+                }
+            }
+            return;
         }
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
@@ -139,7 +167,7 @@ __global__ __launch_bounds__(256, 3) void bn_bwd_conv1_kernel(const Conv1Bwd p) 
         for (int h = 0; h < 2; ++h) {
             const int row = pl + 32 * h;
             const uint32_t gw[4] = {rg[h].x, rg[h].y, rg[h].z, rg[h].w}, yw[4] = {ry[h].x, ry[h].y, ry[h].z, ry[h].w};
-            uint32_t dwd[4];
+            uint32_t dwd[4], gw1[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 uint32_t keep = 0u;
@@ -149,11 +177,27 @@ __global__ __launch_bounds__(256, 3) void bn_bwd_conv1_kernel(const Conv1Bwd p) 
                     const float v = __uint_as_float(e ? (yw[j] & 0xFFFF0000u) : (yw[j] << 16));
                     if (v * sc[i] + sh[i] > 0.f) keep |= e ? 0xFFFF0000u : 0x0000FFFFu;
                 }
-                dwd[j] = gw[j] & keep;
+                dwd[j] = MODE == 0 ? (gw[j] & keep) : (yw[j] & keep);
+                if (MODE == 1) gw1[j] = 0x3F803F80u & keep;
             }
             const int s = c1_swz_a(row);
             *(uint4*)(abase + row * C1_ROWA + ((cg ^ s) << 4)) = make_uint4(dwd[0], dwd[1], dwd[2], dwd[3]);
-            *(uint4*)(abase + row * C1_ROWA + (((8 + cg) ^ s) << 4)) = ry[h];
+            *(uint4*)(abase + row * C1_ROWA + (((8 + cg) ^ s) << 4)) = MODE == 0 ? ry[h] : make_uint4(gw1[0], gw1[1], gw1[2], gw1[3]);
+        }
+        if (MODE == 1) {
+            if (tid < C1_BK) {
+                uint32_t hi[4], lo[4];
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    const float dl = r.hd[o] * r.hr[o] * (1.f - r.hr[o]);
+                    const bf16_t h16 = f2bf(dl);
+                    hi[o] = h16;
+                    lo[o] = f2bf(dl - bf2f(h16));
+                }
+                *(uint4*)(xbase + tid * C1_ROWX + (c1_swz_x(tid) << 4)) =
+                    make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
+            }
+            return;
         }
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
@@ -205,7 +249,7 @@ __global__ __launch_bounds__(256, 3) void bn_bwd_conv1_kernel(const Conv1Bwd p) 
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[i], cb[j], acc[i][j], 0, 0, 0);
                 if (wave == 0) acc1[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[i], ones, acc1[i], 0, 0, 0);
             }
-            accd = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cb[0], cb[1], accd, 0, 0, 0);
+            if (MODE == 0) accd = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cb[0], cb[1], accd, 0, 0, 0);
         }
     };
 
@@ -239,7 +283,7 @@ __global__ __launch_bounds__(256, 3) void bn_bwd_conv1_kernel(const Conv1Bwd p) 
     }
     // accd[r]: d channel 4 (lane >> 4) + r against y channel (lane & 15) of the wave's block: keep the diagonal
     const int r = (lane & 15) - 4 * (lane >> 4);
-    if (r >= 0 && r < 4)
+    if (MODE == 0 && r >= 0 && r < 4)
         out[C1_TROWS * C1_COLS + 16 * wave + (lane & 15)] = r == 0 ? accd[0] : r == 1 ? accd[1] : r == 2 ? accd[2] : accd[3];
 }
 
@@ -269,6 +313,25 @@ __global__ __launch_bounds__(256) void bn_bwd_conv1_combine_kernel(const float* 
     }
 }
 
+// folded [C1_ROWF] of the head form -> sums = [sum g * xhat (64) | sum g (64)], sums_head = [dW (CO x 64) | db (CO)]
+__global__ __launch_bounds__(64) void head_sums_combine_kernel(const float* __restrict__ folded, const float* __restrict__ scale,
+                                                               const float* __restrict__ shift, const float* __restrict__ mean,
+                                                               const float* __restrict__ rstd, const float* __restrict__ w,
+                                                               float* __restrict__ sums, float* __restrict__ sums_head, int CO) {
+    const int c = threadIdx.x;
+    double s_g = 0.0, s_gy = 0.0;
+    for (int o = 0; o < CO; ++o) {
+        const double p2 = (double)folded[c * C1_COLS + o] + (double)folded[c * C1_COLS + 4 + o];
+        const double p1 = (double)folded[(64 + c) * C1_COLS + o] + (double)folded[(64 + c) * C1_COLS + 4 + o];
+        s_g += (double)w[o * 64 + c] * p1;
+        s_gy += (double)w[o * 64 + c] * p2;
+        sums_head[o * 64 + c] = (float)((double)scale[c] * p2 + (double)shift[c] * p1);
+    }
+    sums[c] = (float)((double)rstd[c] * (s_gy - (double)mean[c] * s_g));
+    sums[64 + c] = (float)s_g;
+    if (c < CO) sums_head[CO * 64 + c] = (float)((double)folded[128 * C1_COLS + c] + (double)folded[128 * C1_COLS + 4 + c]);
+}
+
 static int c1_blocks(long npix) {
     const long nt = (npix + C1_BK - 1) / C1_BK;
     return (int)(nt < C1_MAX_BLOCKS ? nt : C1_MAX_BLOCKS);
@@ -278,6 +341,31 @@ static int c1_shift(int v) {
     int s = 0;
     while ((1 << s) < v) ++s;
     return s;
+}
+
+long head_sums_scratch_floats(long npix) { return ((long)c1_blocks(npix) + 1) * C1_ROWF; }
+
+// the sums of vae_head_bwd (norm.hip) on the matrix pipe; scratch: head_sums_scratch_floats(npix) floats
+int head_sums_mfma(const float* drecon, const float* recon, const bf16_t* y, const float* scale, const float* shift,
+                   const float* mean, const float* rstd, const float* w, float* scratch, float* sums, float* sums_head,
+                   long npix, int hw, int CO, hipStream_t s) {
+    Conv1Bwd p = {};
+    p.y = y; p.scale = scale; p.shift = shift; p.mean = mean; p.rstd = rstd; p.part = scratch;
+    p.npix = (int)npix; p.ntile = (int)((npix + C1_BK - 1) / C1_BK);
+    p.drecon = drecon; p.recon = recon; p.hw = hw; p.hwshift = c1_shift(hw);
+    const int nb = c1_blocks(npix);
+    switch (CO) {
+        case 1: hipLaunchKernelGGL((bn_bwd_conv1_kernel<1, 1>), dim3(nb), dim3(256), 0, s, p); break;
+        case 2: hipLaunchKernelGGL((bn_bwd_conv1_kernel<1, 2>), dim3(nb), dim3(256), 0, s, p); break;
+        case 3: hipLaunchKernelGGL((bn_bwd_conv1_kernel<1, 3>), dim3(nb), dim3(256), 0, s, p); break;
+        default: hipLaunchKernelGGL((bn_bwd_conv1_kernel<1, 4>), dim3(nb), dim3(256), 0, s, p); break;
+    }
+    VAE_LAUNCH_CHECK("bn_bwd_conv1_kernel<head>");
+    float* folded = scratch + (long)nb * C1_ROWF;
+    if (int e = vae_sum_partials(scratch, nb, C1_ROWF, folded, 1.0f, (void*)s)) return e;
+    hipLaunchKernelGGL(head_sums_combine_kernel, dim3(1), dim3(64), 0, s, folded, scale, shift, mean, rstd, w, sums, sums_head, CO);
+    VAE_LAUNCH_CHECK("head_sums_combine_kernel");
+    return 0;
 }
 
 }  // namespace vae
@@ -309,9 +397,9 @@ extern "C" int vae_bn_bwd_conv1(const void* gin, const void* y, const void* x8, 
     {
         // gin and y read once, the 8-channel input once
         ProfScope prof("bn_bwd_conv1_kernel", 0.0, (double)npix * (2.0 * 64 * 2 + 16), s);
-        if (Cin == 1) hipLaunchKernelGGL(bn_bwd_conv1_kernel<1>, dim3(nb), dim3(256), 0, s, p);
-        else if (Cin == 2) hipLaunchKernelGGL(bn_bwd_conv1_kernel<2>, dim3(nb), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL(bn_bwd_conv1_kernel<3>, dim3(nb), dim3(256), 0, s, p);
+        if (Cin == 1) hipLaunchKernelGGL((bn_bwd_conv1_kernel<0, 1>), dim3(nb), dim3(256), 0, s, p);
+        else if (Cin == 2) hipLaunchKernelGGL((bn_bwd_conv1_kernel<0, 2>), dim3(nb), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((bn_bwd_conv1_kernel<0, 3>), dim3(nb), dim3(256), 0, s, p);
         VAE_LAUNCH_CHECK("bn_bwd_conv1_kernel");
     }
     float* folded = scratch + (long)nb * C1_ROWF;

@@ -104,7 +104,7 @@ void make_ws_layout(const Dims& d, WsLayout* w) {
     }
     for (int i = 0; i < 3; ++i) w->g[i] = put(npix * 64 * 2);
     w->bnpart = put(1024L * 512 * 4);
-    w->headpart = put(1024L * 7 * 64 * 4);
+    w->headpart = put((long)vae_head_bwd_blocks(d.N, d.S, d.S) * (3 + d.Cout) * 64 * 4);
     w->headsums = put(7 * 64 * 4);
     // every weight-gradient GEMM of a backward stage keeps its own split-K slabs until the stage's single fold launch:
     // the buffer holds all of them side by side (a few hundred MB of 288 GB)

@@ -144,6 +144,12 @@ __global__ __launch_bounds__(1024) void sum_partials_kernel(const float* __restr
 
 // ---------------------------------------------------------------------------------------
 int g_pool_ymax_mode = 0;
+int g_head_sums_mode = 0;
+// bn_conv1_bwd.hip
+long head_sums_scratch_floats(long npix);
+int head_sums_mfma(const float* drecon, const float* recon, const bf16_t* y, const float* scale, const float* shift,
+                   const float* mean, const float* rstd, const float* w, float* scratch, float* sums, float* sums_head,
+                   long npix, int hw, int CO, hipStream_t s);
 
 static int pow2_shift(int v) {
     if (v <= 0 || (v & (v - 1))) return -1;
@@ -767,36 +773,51 @@ extern "C" int vae_head_fwd(const void* y, const float* scale, const float* shif
     return 0;
 }
 
-extern "C" int vae_head_bwd_blocks(int n_img, int H, int W) {
+// workgroups of the vector-ALU form of pass 0
+static int head_bwd_pass0_blocks(long npix) {
     // pass 0 keeps 43 running sums per lane (164 VGPRs): three workgroups share a CU, so 768 is one full round of
     // resident workgroups on 256 CUs (1024 left a second round of 256 that ran alone)
-    long b = ((long)n_img * H * W + 31) / 32;
+    long b = (npix + 31) / 32;
     if (b < 1) b = 1;
     if (b > 768) b = 768;
     return (int)b;
+}
+
+extern "C" int vae_head_bwd_blocks(int n_img, int H, int W) {
+    // rows of 256 floats (the narrowest row a caller multiplies by: (3 + 1) * 64) that hold either form's scratch
+    const long npix = (long)n_img * H * W;
+    const long a = (long)head_bwd_pass0_blocks(npix) * 7 * 64, b = head_sums_scratch_floats(npix);
+    return (int)(((a > b ? a : b) + 255) / 256);
 }
 
 extern "C" int vae_head_bwd(const float* drecon, const float* recon, const void* y, const float* scale,
                             const float* shift, const float* mean, const float* rstd, const float* w, float* partial,
                             float* sums, float* sums_head, void* dy, int n_img, int H, int W, int Cout, void* stream) {
     VAE_CHECK(drecon && recon && y && scale && shift && mean && rstd && w && partial && sums && sums_head && dy, "vae_head_bwd: null pointer");
+    VAE_CHECK(((uintptr_t)partial & 15) == 0, "vae_head_bwd: partial must be 16-byte aligned");
     VAE_CHECK(n_img > 0 && H > 0 && W > 0 && (long)n_img * H * W < (1L << 31), "vae_head_bwd: bad geometry");
     VAE_CHECK(Cout >= 1 && Cout <= 4, "vae_head_bwd: out_channels=%d not supported (1..4)", Cout);
     const long npix = (long)n_img * H * W;
-    const int nb = vae_head_bwd_blocks(n_img, H, W);
+    const int nb = head_bwd_pass0_blocks(npix);
     const int ncols = (3 + Cout) * 64;
     const float inv_count = (float)(1.0 / (double)npix);
     hipStream_t s = (hipStream_t)stream;
     const bf16_t* yy = (const bf16_t*)y;
     ProfScope prof("head_bwd(reduce+apply)", 0.0, npix * (2 * 128.0 + 2 * 8.0 * Cout + 128.0), s);
 #define GO(CO, PASS, NB) hipLaunchKernelGGL((head_bwd_kernel<CO, PASS>), dim3(NB), dim3(256), 0, s, drecon, recon, yy, scale, shift, mean, rstd, w, sums, inv_count, partial, (bf16_t*)dy, npix, H * W, pow2_shift(H * W))
-    switch (Cout) { case 1: GO(1, 0, nb); break; case 2: GO(2, 0, nb); break; case 3: GO(3, 0, nb); break; default: GO(4, 0, nb); }
-    VAE_LAUNCH_CHECK("head_bwd_kernel<0>");
-    // [d gamma | d beta] -> sums (also the coefficients of pass 1); [dW | db] -> sums_head
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(4), dim3(1024), 0, s, partial, nb, 128, ncols, sums, 1.0f);
-    const int nh = Cout * 64 + Cout;
-    hipLaunchKernelGGL(sum_partials_kernel, dim3((nh + 31) / 32), dim3(1024), 0, s, partial + 128, nb, nh, ncols, sums_head, 1.0f);
-    VAE_LAUNCH_CHECK("sum_partials_kernel");
+    if (g_head_sums_mode == 0) {
+        // every sum of pass 0 is a contraction over pixels: on the matrix pipe (bn_conv1_bwd.hip)
+        if (int e = head_sums_mfma(drecon, recon, yy, scale, shift, mean, rstd, w, partial, sums, sums_head, npix, H * W, Cout, s))
+            return e;
+    } else {
+        switch (Cout) { case 1: GO(1, 0, nb); break; case 2: GO(2, 0, nb); break; case 3: GO(3, 0, nb); break; default: GO(4, 0, nb); }
+        VAE_LAUNCH_CHECK("head_bwd_kernel<0>");
+        // [d gamma | d beta] -> sums (also the coefficients of pass 1); [dW | db] -> sums_head
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(4), dim3(1024), 0, s, partial, nb, 128, ncols, sums, 1.0f);
+        const int nh = Cout * 64 + Cout;
+        hipLaunchKernelGGL(sum_partials_kernel, dim3((nh + 31) / 32), dim3(1024), 0, s, partial + 128, nb, nh, ncols, sums_head, 1.0f);
+        VAE_LAUNCH_CHECK("sum_partials_kernel");
+    }
     const int nb2 = (int)((npix + 31) / 32 > 2048 ? 2048 : (npix + 31) / 32);
     switch (Cout) { case 1: GO(1, 1, nb2); break; case 2: GO(2, 1, nb2); break; case 3: GO(3, 1, nb2); break; default: GO(4, 1, nb2); }
 #undef GO
