@@ -10,13 +10,15 @@
 //   dW = scale * (T1 - mean(d) * T2 - mean(d * xh) * T3),
 //   T1[co][j] = sum_p d[p][co] X[p][j],   T2[j] = sum_p X[p][j],   T3[co][j] = rstd * (sum_p y[p][co] X[p][j] - mean * T2[j]).
 // One kernel reads gin and y once and accumulates everything on the matrix pipe -- T1, sum y X, T2 and, for d gamma
-// and d beta, sum d (a column of ones in X) and sum d * y (the diagonal of d^T y): per 64-pixel tile the bf16 values [d | y] (128 columns, d is exact in bf16:
-// it is gin or 0) and the 27 shifted input values of each pixel go to LDS, and the K = pixel contraction runs as
-// 16x16x32 MFMAs on transposing LDS reads; T2 comes from a constant all-ones operand built in registers.  Neither g
+// and d beta, sum d (a column of ones in X) and sum d * y (the diagonal of d^T y): per 64-pixel tile the bf16 values
+// [d | y] (128 columns, d is exact in bf16: it is gin or 0) and the 9 x Cin shifted input values of each pixel go to
+// LDS, and the K = pixel contraction runs as 16x16x32 MFMAs on transposing LDS reads; T2 comes from a constant
+// all-ones operand built in registers.  Neither g
 // nor any other full-size tensor is written: against the separate BatchNorm-backward passes plus the weight-gradient
 // GEMM this drops one write and two reads of the [pixels][64] tensor and three launches.
 // Every workgroup leaves one row of partial results; vae_sum_partials folds the rows (fixed order, fp64) and a
 // one-workgroup kernel forms dW, d gamma and d beta.
+// The same contraction with other tiles gives the per-channel sums of the 1x1 head's backward (MODE 1 below).
 #include "common.h"
 #include "prof.h"
 #include "../../include/vae_hip.h"
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(256, 3) void bn_bwd_conv1_kernel(const Conv1Bwd p) 
     for (int i = 0; i < 8; ++i) { sc[i] = p.scale[c0 + i]; sh[i] = p.shift[c0 + i]; }
 
     // registers of the tile in flight: two pixels x (gin, y) of this lane's channel group, up to three (pixel, tap) pairs
-    // (a second set in flight cost a resident workgroup per CU in registers and was slower: 46 vs 38 us at batch 512)
+    // (a second set in flight, so that memory is never idle, measured slower in every form tried: 40-46 vs 32-38 us)
     struct InFlight {
         uint4 g[2], y[2];
         uint2 x[3];
