@@ -255,19 +255,26 @@ __global__ __launch_bounds__(256, 3) void bn_bwd_conv1_kernel(const Conv1Bwd p) 
         }
     };
 
+    // A tile's registers are free as soon as it is staged: the loads of the tile after next go out right then and have
+    // the barrier and the next tile's matrix work to land.
     const int G = gridDim.x;
     int tile = blockIdx.x;
     fetch(r0, tile);
     __syncthreads();                       // the clear and the ones column are complete
     deposit(r0, 0);
+    if (tile + G < p.ntile) fetch(r0, tile + G);
     barrier_keep_copies();
     int buf = 0;
-    for (; tile < p.ntile; tile += G) {
-        const bool more = tile + G < p.ntile;
-        if (more) fetch(r0, tile + G);
+    while (true) {
         compute(buf);
-        if (more) deposit(r0, buf ^ 1);
+        const bool more = tile + G < p.ntile;
+        if (more) {
+            deposit(r0, buf ^ 1);
+            if (tile + 2 * G < p.ntile) fetch(r0, tile + 2 * G);
+        }
         barrier_keep_copies();             // stage buf is read out, stage buf ^ 1 is written
+        if (!more) break;
+        tile += G;
         buf ^= 1;
     }
 
