@@ -63,7 +63,8 @@ int vae_prof_stop(char* names, int* launches, double* total_ms, double* flops, d
  * its geometry allows (16- or 32-wide images, whole 256-pixel tiles), 3 as 0 with a hand-pipelined K loop (faster alone, not in the step on every box); "conv1_bwd" = 0 the whole-model backward runs
  * the first conv's BatchNorm backward and weight gradient as vae_bn_bwd_conv1 where Cin <= 3 (default), 1 as separate passes;
  * "pool_ymax" = 0 the whole-model passes keep the conv output at each pooling window's maximum for the backward sums (default), 1 they
- * re-read the windows; "head_sums" = 0 vae_head_bwd forms its per-channel sums on the matrix pipe (default), 1 in vector registers.  Not thread-safe: set it while nothing is being
+ * re-read the windows; "head_sums" = 0 vae_head_bwd forms its per-channel sums on the matrix pipe (default), 1 in vector registers; "fold_defer" = 0
+ * vae_model_backward(stage = -1) folds every split-K slab in one launch at its end (default), 1 in one launch per stage.  Not thread-safe: set it while nothing is being
  * launched. */
 int vae_set_tuning(const char* key, int value);
 /* Diagnostic aid: device buffer (>= 128 bytes per workgroup of the launch under study) that the diagnostic kernel
@@ -205,7 +206,7 @@ int vae_reduce_slabs_scatter(const float* slab, int nsplit, long slab_stride, lo
                              const long* limits4, long base, int accumulate, void* stream);
 /* Several vae_reduce_slabs_scatter folds in one launch (all the weight gradients of a backward stage:
  * the folds are a few microseconds each and only the optimizer waits for them). */
-#define VAE_MAX_REDUCE_JOBS 12
+#define VAE_MAX_REDUCE_JOBS 16
 typedef struct vae_reduce_job {
     const float* slab;
     int nsplit;

@@ -66,6 +66,7 @@ extern int g_conv3_ws64_mode;
 extern int g_conv1_bwd_mode;
 extern int g_pool_ymax_mode;
 extern int g_head_sums_mode;
+extern int g_fold_defer_mode;
 extern unsigned long long* g_conv3_dbg;
 }
 // Diagnostic aid: a device buffer that diagnostic kernel variants write cycle stamps to (null = none).
@@ -101,6 +102,10 @@ extern "C" int vae_set_tuning(const char* key, int value) {
     }
     if (key && !strcmp(key, "head_sums")) {           // the 1x1 head's backward sums: 0 on the matrix pipe, 1 in vector registers
         vae::g_head_sums_mode = value;
+        return 0;
+    }
+    if (key && !strcmp(key, "fold_defer")) {          // whole-pass backward: 0 one slab-fold launch at the end, 1 one per stage
+        vae::g_fold_defer_mode = value;
         return 0;
     }
     if (key && !strcmp(key, "stream_gemm")) {         // 0 the streaming GEMM where it pays, 1 never (tiled GEMM), 2 wherever legal

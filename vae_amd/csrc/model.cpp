@@ -15,7 +15,7 @@
 
 #include "model_layout.h"
 
-namespace vae { extern int g_conv1_bwd_mode; extern int g_pool_ymax_mode; }
+namespace vae { extern int g_conv1_bwd_mode; extern int g_pool_ymax_mode; int g_fold_defer_mode = 0; }
 
 namespace {
 using namespace vae_model;
@@ -407,6 +407,7 @@ struct Fork {
     vae_reduce_job jobs[VAE_MAX_REDUCE_JOBS];
     int njobs;
     long slab_used;      // floats
+    bool defer;          // whole backward pass in one call: every fold waits for ONE launch at its end
 };
 
 static const int N_EVENTS = 64;
@@ -435,6 +436,7 @@ static int fork_init(Fork* f, void* main, void* side) {
     f->n = 0;
     f->njobs = 0;
     f->slab_used = 0;
+    f->defer = false;
     f->ev = f->two ? event_pool() : nullptr;
     CHECK(!f->two || f->ev, "vae_model_backward: could not create the events that order the two streams");
     return 0;
@@ -480,7 +482,8 @@ static int fold_later(Fork* f, const float* slab, int ns, long stride, long slab
     return 0;
 }
 // fold everything recorded so far, on the stream the weight gradients run on; the slab buffer is free again after it
-static int flush_folds(Fork* f) {
+static int flush_folds(Fork* f, bool last = false) {
+    if (f->defer && !last) return 0;
     if (f->njobs > 0) TRY(vae_multi_reduce_slabs_scatter(f->jobs, f->njobs, f->side));
     f->njobs = 0;
     f->slab_used = 0;
@@ -650,6 +653,7 @@ extern "C" int vae_model_backward(const vae_model_cfg* cfg, const float* params,
     c.params = (float*)params; c.grads = grads; c.wpack = (char*)wpack; c.w = (char*)workspace; c.stream = stream;
     Fork f;
     TRY(fork_init(&f, stream, cfg->side_stream));
+    f.defer = stage == -1 && vae::g_fold_defer_mode == 0;
     hipEvent_t carry = nullptr;
     if (stage == -1 || stage == 0)
         TRY(backward_decoder(c, &f, d_recon, recon, mu, logvar, eps_in, dmu_ext, dlv_ext, kl_scale));
@@ -661,7 +665,7 @@ extern "C" int vae_model_backward(const vae_model_cfg* cfg, const float* params,
     if (stage == -1 || stage == 2) {
         TRY(backward_block(c, &f, 1, keep_masks, &carry));
         TRY(backward_block(c, &f, 0, keep_masks, &carry));
-        TRY(flush_folds(&f));
+        TRY(flush_folds(&f, true));
     }
     // join: whatever the caller enqueues next on `stream` (all-reduce of this stage, the optimizer) sees every gradient
     hipEvent_t last;
