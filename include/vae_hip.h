@@ -206,7 +206,7 @@ int vae_reduce_slabs_scatter(const float* slab, int nsplit, long slab_stride, lo
                              const long* limits4, long base, int accumulate, void* stream);
 /* Several vae_reduce_slabs_scatter folds in one launch (all the weight gradients of a backward stage:
  * the folds are a few microseconds each and only the optimizer waits for them). */
-#define VAE_MAX_REDUCE_JOBS 16
+#define VAE_MAX_REDUCE_JOBS 20
 typedef struct vae_reduce_job {
     const float* slab;
     int nsplit;

@@ -558,7 +558,8 @@ static int backward_decoder(const Ctx& c, Fork* f, const float* d_recon, const f
     const int nr = vae_tanh_bwd_rows(d.N);
     TRY(vae_tanh_bwd(c.at(w.g[x]), c.at(w.h), c.at(w.dpre), (float*)c.at(w.colp), d.N, d.F, c.stream));
     // fc_up.bias grad: column sums, NHWC order -> parameter order via a permuting reduce
-    TRY(reduce4((float*)c.at(w.colp), nr, d.F, 0, c.G(P_FC_UP_B), 1, d.hw, 256, 1, 0, 1, d.hw, 0, c.stream));
+    // (a sum over rows is a fold of `rows` slabs of one row each: it rides in the stage's fold launch)
+    TRY(fold_later(f, (float*)c.at(w.colp), nr, d.F, 0, c.G(P_FC_UP_B), 1, d.hw, 256, 1, 0, 1, d.hw, 0));
     TRY(side_after_main(f));
     TRY(wgrad_to(c, f, &slab, c.at(w.dpre), c.at(w.zb), d.F, d.L, d.N, d.F, d.L, VAE_WGRAD_PLAIN, 1, 1, 1, &ns, sd));
     // slab [(p, c)][l] -> fc_up.weight [(c, p)][l]
@@ -567,8 +568,9 @@ static int backward_decoder(const Ctx& c, Fork* f, const float* d_recon, const f
     TRY(vae_reparam_kl_bwd((const float*)c.at(w.dz), mu, logvar, eps_in, dmu_ext, dlv_ext, kl_scale, (float*)c.at(w.dmu),
                            (float*)c.at(w.dlv), c.at(w.dcat), (long)d.N * d.L, d.L, c.cfg->seed, c.cfg->step, c.cfg->rank,
                            c.stream));
-    TRY(vae_sum_partials((const float*)c.at(w.dmu), d.N, d.L, c.G(P_FC_MU_B), 1.0f, c.stream));
-    TRY(vae_sum_partials((const float*)c.at(w.dlv), d.N, d.L, c.G(P_FC_LV_B), 1.0f, c.stream));
+    // fc_mu.bias / fc_logvar.bias gradients: column sums of d mu, d logvar
+    TRY(fold_later(f, (const float*)c.at(w.dmu), d.N, d.L, 0, c.G(P_FC_MU_B), 1, 1, 1, d.L, 0, 0, 0, 1));
+    TRY(fold_later(f, (const float*)c.at(w.dlv), d.N, d.L, 0, c.G(P_FC_LV_B), 1, 1, 1, d.L, 0, 0, 0, 1));
     TRY(side_after_main(f));
     TRY(wgrad_to(c, f, &slab, c.at(w.dcat), c.at(w.ob[3]), 2 * d.L, d.F, d.N, 2 * d.L, d.F, VAE_WGRAD_PLAIN, 1, 1, 1, &ns, sd));
     for (int t = 0; t < 2; ++t)
