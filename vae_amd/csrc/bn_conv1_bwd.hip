@@ -16,8 +16,8 @@
 // all-ones operand built in registers.  Neither g
 // nor any other full-size tensor is written: against the separate BatchNorm-backward passes plus the weight-gradient
 // GEMM this drops one write and two reads of the [pixels][64] tensor and three launches.
-// Every workgroup leaves one row of partial results; vae_sum_partials folds the rows (fixed order, fp64) and a
-// one-workgroup kernel forms dW, d gamma and d beta.
+// Every workgroup leaves one row of partial results; a second kernel (one workgroup per output channel) folds the rows
+// in fp64 and fixed order and forms dW, d gamma and d beta.
 // The same contraction with other tiles gives the per-channel sums of the 1x1 head's backward (MODE 1 below).
 #include "common.h"
 #include "prof.h"
@@ -296,49 +296,82 @@ __global__ __launch_bounds__(256, 3) void bn_bwd_conv1_kernel(const Conv1Bwd p) 
         out[C1_TROWS * C1_COLS + 16 * wave + (lane & 15)] = r == 0 ? accd[0] : r == 1 ? accd[1] : r == 2 ? accd[2] : accd[3];
 }
 
-// folded [C1_ROWF] -> dW [64][Cin][9], sums = [d gamma (64) | d beta (64)]
-__global__ __launch_bounds__(256) void bn_bwd_conv1_combine_kernel(const float* __restrict__ folded,
-                                                                   const float* __restrict__ scale,
-                                                                   const float* __restrict__ mean,
-                                                                   const float* __restrict__ rstd, double inv_count,
-                                                                   float* __restrict__ sums, float* __restrict__ dW, int Cin) {
-    const float* st = folded + C1_TROWS * C1_COLS;          // sum d * y; sum d = T1[c][31]
-    for (int o = threadIdx.x; o < 64 * 9 * Cin; o += 256) {
-        const int co = o / (9 * Cin), rem = o - co * 9 * Cin;
-        const int ci = rem / 9, tap = rem - ci * 9;
-        const int col = tap * Cin + ci;
-        const double t1 = folded[co * C1_COLS + col], ty = folded[(64 + co) * C1_COLS + col], t2 = folded[128 * C1_COLS + col];
-        const double t3 = (double)rstd[co] * (ty - (double)mean[co] * t2);
-        const double s_d = folded[co * C1_COLS + 31];
-        const double s_dx = (double)rstd[co] * ((double)st[co] - (double)mean[co] * s_d);      // sum d * xhat
-        const double m_dx = s_dx * inv_count, m_d = s_d * inv_count;
-        dW[o] = (float)((double)scale[co] * (t1 - m_d * t2 - m_dx * t3));
+// The tail of both forms in ONE launch: workgroup c folds, over the nb partial rows, the T rows channel c needs (c,
+// 64 + c, the ones row and -- first conv -- its sum d * y) in fp64 and fixed order, then forms channel c's results.
+//   MODE 0: dW[c][Cin][9] and sums = [d gamma (64) | d beta (64)];  out2 = dW
+//   MODE 1: sums = [sum g * xhat (64) | sum g (64)], out2 = sums_head = [dW (CO x 64) | db (CO)]
+// block = 1024 = 32 columns x 32 row groups; a launch like this is a chain of memory round trips, so eight rows are
+// requested at a time.
+template <int MODE>
+__global__ __launch_bounds__(1024) void c1_fold_kernel(const float* __restrict__ part, int nb, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd, const float* __restrict__ w,
+                                                       double inv_count, float* __restrict__ sums, float* __restrict__ out2,
+                                                       int NC) {
+    constexpr int NQ = MODE == 0 ? 4 : 3;
+    __shared__ double red[NQ][32][33];
+    __shared__ double T[4][32];
+    const int c = blockIdx.x, col = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    // the NQ rows are folded side by side: all their loads of a batch of eight partial rows are in flight together
+    long off[NQ];
+    double acc[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        off[q] = (q == 0 ? c * C1_COLS : q == 1 ? (64 + c) * C1_COLS : q == 2 ? 128 * C1_COLS : C1_TROWS * C1_COLS + c) +
+                 (q < 3 ? col : 0);            // the fourth row is one value: every lane reads it, lane 0's copy is used
+        acc[q] = 0.0;
     }
-    if (threadIdx.x < 64) {
-        const int c = threadIdx.x;
-        const double s_d = folded[c * C1_COLS + 31];
-        sums[c] = (float)((double)rstd[c] * ((double)st[c] - (double)mean[c] * s_d));
-        sums[64 + c] = (float)s_d;
+    int r = rg;
+    for (; r + 224 < nb; r += 256) {
+        float v[NQ][8];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[q][i] = part[(long)(r + 32 * i) * C1_ROWF + off[q]];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+            acc[q] += (((double)v[q][0] + (double)v[q][1]) + ((double)v[q][2] + (double)v[q][3])) +
+                      (((double)v[q][4] + (double)v[q][5]) + ((double)v[q][6] + (double)v[q][7]));
     }
-}
-
-// folded [C1_ROWF] of the head form -> sums = [sum g * xhat (64) | sum g (64)], sums_head = [dW (CO x 64) | db (CO)]
-__global__ __launch_bounds__(64) void head_sums_combine_kernel(const float* __restrict__ folded, const float* __restrict__ scale,
-                                                               const float* __restrict__ shift, const float* __restrict__ mean,
-                                                               const float* __restrict__ rstd, const float* __restrict__ w,
-                                                               float* __restrict__ sums, float* __restrict__ sums_head, int CO) {
-    const int c = threadIdx.x;
-    double s_g = 0.0, s_gy = 0.0;
-    for (int o = 0; o < CO; ++o) {
-        const double p2 = (double)folded[c * C1_COLS + o] + (double)folded[c * C1_COLS + 4 + o];
-        const double p1 = (double)folded[(64 + c) * C1_COLS + o] + (double)folded[(64 + c) * C1_COLS + 4 + o];
-        s_g += (double)w[o * 64 + c] * p1;
-        s_gy += (double)w[o * 64 + c] * p2;
-        sums_head[o * 64 + c] = (float)((double)scale[c] * p2 + (double)shift[c] * p1);
+    for (; r < nb; r += 32)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[q] += (double)part[(long)r * C1_ROWF + off[q]];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) red[q][rg][col] = acc[q];
+    __syncthreads();
+    if (rg < NQ) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) t += red[rg][i][col];
+        T[rg][col] = t;
     }
-    sums[c] = (float)((double)rstd[c] * (s_gy - (double)mean[c] * s_g));
-    sums[64 + c] = (float)s_g;
-    if (c < CO) sums_head[CO * 64 + c] = (float)((double)folded[128 * C1_COLS + c] + (double)folded[128 * C1_COLS + 4 + c]);
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (MODE == 0) {
+        const int Cin = NC;
+        const double s_d = T[0][31];
+        const double s_dx = (double)rstd[c] * (T[3][0] - (double)mean[c] * s_d);      // sum d * xhat
+        if (t < 9 * Cin) {
+            const int ci = t / 9, tap = t - ci * 9, j = tap * Cin + ci;
+            const double t3 = (double)rstd[c] * (T[1][j] - (double)mean[c] * T[2][j]);
+            out2[c * 9 * Cin + t] = (float)((double)scale[c] * (T[0][j] - s_d * inv_count * T[2][j] - s_dx * inv_count * t3));
+        }
+        if (t == 0) { sums[c] = (float)s_dx; sums[64 + c] = (float)s_d; }
+    } else {
+        const int CO = NC;
+        if (t == 0) {
+            double s_g = 0.0, s_gy = 0.0;
+            for (int o = 0; o < CO; ++o) {
+                const double p2 = T[0][o] + T[0][4 + o], p1 = T[1][o] + T[1][4 + o];
+                s_g += (double)w[o * 64 + c] * p1;
+                s_gy += (double)w[o * 64 + c] * p2;
+                out2[o * 64 + c] = (float)((double)scale[c] * p2 + (double)shift[c] * p1);
+            }
+            sums[c] = (float)((double)rstd[c] * (s_gy - (double)mean[c] * s_g));
+            sums[64 + c] = (float)s_g;
+            if (c < CO) out2[CO * 64 + c] = (float)(T[2][c] + T[2][4 + c]);
+        }
+    }
 }
 
 static int c1_blocks(long npix) {
@@ -370,10 +403,8 @@ int head_sums_mfma(const float* drecon, const float* recon, const bf16_t* y, con
         default: hipLaunchKernelGGL((bn_bwd_conv1_kernel<1, 4>), dim3(nb), dim3(256), 0, s, p); break;
     }
     VAE_LAUNCH_CHECK("bn_bwd_conv1_kernel<head>");
-    float* folded = scratch + (long)nb * C1_ROWF;
-    if (int e = vae_sum_partials(scratch, nb, C1_ROWF, folded, 1.0f, (void*)s)) return e;
-    hipLaunchKernelGGL(head_sums_combine_kernel, dim3(1), dim3(64), 0, s, folded, scale, shift, mean, rstd, w, sums, sums_head, CO);
-    VAE_LAUNCH_CHECK("head_sums_combine_kernel");
+    hipLaunchKernelGGL(c1_fold_kernel<1>, dim3(64), dim3(1024), 0, s, scratch, nb, scale, shift, mean, rstd, w, 0.0, sums, sums_head, CO);
+    VAE_LAUNCH_CHECK("c1_fold_kernel<head>");
     return 0;
 }
 
@@ -411,10 +442,8 @@ extern "C" int vae_bn_bwd_conv1(const void* gin, const void* y, const void* x8, 
         else hipLaunchKernelGGL((bn_bwd_conv1_kernel<0, 3>), dim3(nb), dim3(256), 0, s, p);
         VAE_LAUNCH_CHECK("bn_bwd_conv1_kernel");
     }
-    float* folded = scratch + (long)nb * C1_ROWF;
-    if (int e = vae_sum_partials(scratch, nb, C1_ROWF, folded, 1.0f, stream)) return e;
-    hipLaunchKernelGGL(bn_bwd_conv1_combine_kernel, dim3(1), dim3(256), 0, s, folded, scale, mean, rstd, 1.0 / (double)npix,
-                       sums, dW, Cin);
-    VAE_LAUNCH_CHECK("bn_bwd_conv1_combine_kernel");
+    hipLaunchKernelGGL(c1_fold_kernel<0>, dim3(64), dim3(1024), 0, s, scratch, nb, scale, shift, mean, rstd, (const float*)nullptr,
+                       1.0 / (double)npix, sums, dW, Cin);
+    VAE_LAUNCH_CHECK("c1_fold_kernel");
     return 0;
 }
