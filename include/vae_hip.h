@@ -369,6 +369,10 @@ int vae_tanh_bwd(const void* dx, const void* h, void* dpre, float* colpartial, i
                  void* stream);
 /* inputs.to(device) (train.py:325): NCHW f32 image batch -> NHWC bf16 padded to 8 channels */
 int vae_nchw_to_nhwc8(const float* x, void* out, int n_img, int C, int H, int W, void* stream);
+/* the same, also adding 1 to counters[0 .. ncount) (int64, device; BatchNorm2d.num_batches_tracked of a train-mode
+ * forward pass): the first kernel of the pass does it on the way.  counters may be null. */
+int vae_nchw_to_nhwc8_count(const float* x, void* out, int n_img, int C, int H, int W, long long* counters, int ncount,
+                            void* stream);
 /* Batch feed from a dataset resident in HBM: out[b][c][h][w] = data[index[b]][h][w][c] / 255 (fp32, the
  * value torchvision's ToTensor gives).  Replaces the host-side batch assembly of the reference's DataLoader
  * (vae/training/train.py:158-179: random_split + DataLoader(shuffle); :266-274: CIFAR10 / ToTensor).
@@ -409,6 +413,11 @@ typedef struct vae_model_cfg {
                               * buffers; vae_model_workspace_bytes depends on it.  In this mode vae_model_backward
                               * writes all 52 gradients (the biases in front of a BatchNorm get their rounding-noise
                               * sums, as in the reference) and ignores side_stream. */
+    long long* batches_tracked;  /* optional, device: the eleven BatchNorm2d.num_batches_tracked counters in module order
+                              * (conv1.net.1 ... conv4.net.4, bn3, bn2, bn1).  With train != 0 and the bf16 path,
+                              * vae_model_forward adds 1 to all of them and vae_model_encode to the first eight, as
+                              * nn.BatchNorm2d.forward does in train mode (vae/models/vae.py:26,32,57-72), inside a
+                              * kernel it launches anyway.  NULL (or the fp32 path): the caller keeps the counters. */
 } vae_model_cfg;
 #define VAE_PRECISION_BF16 0
 #define VAE_PRECISION_FP32 1

@@ -92,6 +92,7 @@ SIGNATURES = {
     "vae_tanh_bwd_rows": (c_int, [c_int]),
     "vae_tanh_bwd": (None, [P, P, P, P, c_int, c_int, P]),
     "vae_nchw_to_nhwc8": (None, [P, P, c_int, c_int, c_int, c_int, P]),
+    "vae_nchw_to_nhwc8_count": (None, [P, P, c_int, c_int, c_int, c_int, P, c_int, P]),
     "vae_feed_u8": (None, [P, c_long, P, P, c_int, c_int, c_int, c_int, P]),
     "vae_adamw_grid": (c_int, [c_long]),
     "vae_adamw_clip_step": (None, [P, P, P, P, c_long, P, c_float, c_float, c_double, c_double, c_double,
@@ -117,7 +118,7 @@ class ModelCfg(ctypes.Structure):
     _fields_ = [("batch", c_int), ("in_channels", c_int), ("out_channels", c_int), ("latent", c_int),
                 ("image_size", c_int), ("train", c_int), ("p_dropout", c_double),
                 ("seed", c_ulonglong), ("step", c_uint), ("rank", c_uint), ("side_stream", c_void_p),
-                ("precision", c_int)]
+                ("precision", c_int), ("batches_tracked", c_void_p)]
 
 
 PRECISIONS = {"bf16": 0, "fp32": 1}      # VAE_PRECISION_* of include/vae_hip.h

@@ -300,14 +300,15 @@ static int decoder_forward(const Ctx& c, float* recon) {
                         d.Cout, c.stream);
 }
 
-static int encoder_forward(const Ctx& c, const float* x, const void* const* masks, float* mu, float* logvar) {
+static int encoder_forward(const Ctx& c, const float* x, const void* const* masks, float* mu, float* logvar, int nbn) {
     const Dims& d = c.d;
     const WsLayout& w = c.ws;
     const int train = c.cfg->train;
     const double p = train ? c.cfg->p_dropout : 0.0;
     float* ss = train ? (float*)c.at(w.stat_sum) : nullptr;
     float* sq = train ? (float*)c.at(w.stat_sq) : nullptr;
-    TRY(vae_nchw_to_nhwc8(x, c.at(w.x8), d.N, d.Cin, d.S, d.S, c.stream));
+    // (num_batches_tracked of the nbn BatchNorm layers this pass runs in train mode)
+    TRY(vae_nchw_to_nhwc8_count(x, c.at(w.x8), d.N, d.Cin, d.S, d.S, train ? c.cfg->batches_tracked : nullptr, nbn, c.stream));
     const void* in = c.at(w.x8);
     for (int b = 0; b < 4; ++b) {
         const int H = d.S >> b, C = ENC_C[b];
@@ -347,7 +348,7 @@ extern "C" int vae_model_forward(const vae_model_cfg* cfg, const float* params, 
     }
     CHECK(params && bn_stats && wpack && workspace && x && recon && mu && logvar, "vae_model_forward: null pointer");
     c.params = (float*)params; c.bn = bn_stats; c.wpack = (char*)wpack; c.w = (char*)workspace; c.stream = stream;
-    TRY(encoder_forward(c, x, keep_masks, mu, logvar));
+    TRY(encoder_forward(c, x, keep_masks, mu, logvar, 11));
     TRY(vae_reparam_kl_fwd(mu, logvar, eps_in, nullptr, c.at(c.ws.zb), nullptr, (float*)c.at(c.ws.klp),
                            (long)c.d.N * c.d.L, cfg->seed, cfg->step, cfg->rank, stream));
     return decoder_forward(c, recon);
@@ -364,7 +365,7 @@ extern "C" int vae_model_encode(const vae_model_cfg* cfg, const float* params, f
     }
     CHECK(params && bn_stats && wpack && workspace && x && mu && logvar, "vae_model_encode: null pointer");
     c.params = (float*)params; c.bn = bn_stats; c.wpack = (char*)wpack; c.w = (char*)workspace; c.stream = stream;
-    return encoder_forward(c, x, keep_masks, mu, logvar);
+    return encoder_forward(c, x, keep_masks, mu, logvar, 8);
 }
 
 extern "C" int vae_model_decode(const vae_model_cfg* cfg, const float* params, float* bn_stats, const void* wpack,

@@ -598,7 +598,9 @@ __global__ __launch_bounds__(256) void tanh_bwd_kernel(const bf16_t* __restrict_
 
 // network input NCHW fp32 (C <= 8) -> NHWC bf16 padded to 8 channels
 __global__ __launch_bounds__(256) void nchw_to_nhwc8_kernel(const float* __restrict__ x, bf16_t* __restrict__ out,
-                                                            long npix, int C, int hw) {
+                                                            long npix, int C, int hw, long long* __restrict__ counters,
+                                                            int ncount) {
+    if (counters && blockIdx.x == 0 && (int)threadIdx.x < ncount) counters[threadIdx.x] += 1;
     for (long pix = (long)blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += (long)gridDim.x * blockDim.x) {
         const long img = pix / hw, p = pix % hw;
         float v[8];
@@ -838,11 +840,17 @@ extern "C" int vae_tanh_bwd(const void* dx, const void* h, void* dpre, float* co
 }
 
 extern "C" int vae_nchw_to_nhwc8(const float* x, void* out, int n_img, int C, int H, int W, void* stream) {
+    return vae_nchw_to_nhwc8_count(x, out, n_img, C, H, W, nullptr, 0, stream);
+}
+
+extern "C" int vae_nchw_to_nhwc8_count(const float* x, void* out, int n_img, int C, int H, int W, long long* counters,
+                                       int ncount, void* stream) {
     VAE_CHECK(x && out && n_img > 0 && H > 0 && W > 0, "vae_nchw_to_nhwc8: bad arguments");
+    VAE_CHECK(ncount >= 0 && ncount <= 256 && (((uintptr_t)counters) & 7) == 0, "vae_nchw_to_nhwc8_count: bad counters");
     VAE_CHECK(C >= 1 && C <= 8, "vae_nchw_to_nhwc8: in_channels=%d not supported (1..8)", C);
     const long npix = (long)n_img * H * W;
     hipLaunchKernelGGL(nchw_to_nhwc8_kernel, dim3(elem_grid(npix)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)out,
-                       npix, C, H * W);
+                       npix, C, H * W, counters, ncount);
     VAE_LAUNCH_CHECK("nchw_to_nhwc8_kernel");
     return 0;
 }

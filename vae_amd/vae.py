@@ -153,7 +153,17 @@ class VAEConv(nn.Module):
                              latent=hp["latent_dims"], image_size=hp["image_size"], train=int(train),
                              p_dropout=hp["p_dropout"], seed=int(self.rng_seed),
                              step=int(self.rng_step if step is None else step) & 0xFFFFFFFF, rank=int(self.rank),
-                             side_stream=side, precision=_lib.PRECISIONS[self.precision])
+                             side_stream=side, precision=_lib.PRECISIONS[self.precision],
+                             batches_tracked=self._nbt_ptr(train))
+
+    def _nbt_ptr(self, train: bool):
+        """device address of the eleven num_batches_tracked counters when the library bumps them itself (train mode,
+        bf16 path, counters in one int64 tensor on the device), else None: then the Python side adds 1"""
+        t = self._nbt
+        if train and self.precision == "bf16" and t is not None and t.is_cuda and t.dtype == torch.int64 and t.is_contiguous() \
+                and t.numel() == 11:
+            return t.data_ptr()
+        return None
 
     def _flatten(self, device):
         """Move parameters / running stats into the flat buffers the kernels use (views keep
@@ -304,7 +314,8 @@ class VAEConv(nn.Module):
                   self._wpack.data_ptr(), ws.data_ptr(), x.data_ptr(), _lib.ptr(eps), marr, recon.data_ptr(),
                   mu.data_ptr(), logvar.data_ptr(), _lib.current_stream())
         if train:
-            self._nbt += 1
+            if not cfg.batches_tracked:
+                self._nbt += 1
             self.rng_step += 1
         state = dict(cfg=cfg, ws=ws, x=x, eps=eps, marr=marr, masks=mkeep, recon=recon, mu=mu, logvar=logvar, batch=N)
         self._last = state
@@ -353,7 +364,8 @@ class VAEConv(nn.Module):
                   self._wpack.data_ptr(), ws.data_ptr(), x.data_ptr(), None, mu.data_ptr(), logvar.data_ptr(),
                   _lib.current_stream())
         if self.training:
-            self._nbt[:8] += 1
+            if not cfg.batches_tracked:
+                self._nbt[:8] += 1
             self.rng_step += 1
         self._release_workspace(N, ws)
         return mu, logvar
