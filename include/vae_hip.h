@@ -64,7 +64,9 @@ int vae_prof_stop(char* names, int* launches, double* total_ms, double* flops, d
  * the first conv's BatchNorm backward and weight gradient as vae_bn_bwd_conv1 where Cin <= 3 (default), 1 as separate passes;
  * "pool_ymax" = 0 the whole-model passes keep the conv output at each pooling window's maximum for the backward sums (default), 1 they
  * re-read the windows; "head_sums" = 0 vae_head_bwd forms its per-channel sums on the matrix pipe (default), 1 in vector registers; "fold_defer" = 0
- * vae_model_backward(stage = -1) folds every split-K slab in one launch at its end (default), 1 in one launch per stage.  Not thread-safe: set it while nothing is being
+ * vae_model_backward(stage = -1) folds every split-K slab in one launch at its end (default), 1 in one launch per stage;
+ * "slab_reparam" = 0 the whole-model passes let the reparameterisation kernels add up the split-K slabs of the latent GEMMs
+ * (default), 1 a finishing kernel does.  Not thread-safe: set it while nothing is being
  * launched. */
 int vae_set_tuning(const char* key, int value);
 /* Diagnostic aid: device buffer (>= 128 bytes per workgroup of the launch under study) that the diagnostic kernel
@@ -105,6 +107,13 @@ int vae_reparam_grid(long n_elems);
 int vae_reparam_kl_fwd(const float* mu, const float* logvar, const float* eps_in, float* z_f32,
                        void* z_bf16, float* eps_out, float* kl_partial, long n_elems,
                        unsigned long long seed, unsigned step, unsigned rank, void* stream);
+/* The same fed by the split-K slabs of the fc_mu | fc_logvar GEMM (vae_linear_gemm_splitk with out == NULL):
+ * mu | logvar [rows][latent] are OUTPUTS here, = bias[2 latent] + the nsplit slabs [s][row][2 latent] added in slab
+ * order (exactly what the GEMM's own finishing step writes), then as above. */
+int vae_reparam_kl_fwd_slabs(const float* slab, int nsplit, const float* bias, float* mu, float* logvar,
+                             const float* eps_in, float* z_f32, void* z_bf16, float* eps_out, float* kl_partial,
+                             long n_elems, int latent, unsigned long long seed, unsigned step, unsigned rank,
+                             void* stream);
 /* dmu = dz + dmu_ext + kl_scale*mu ; dlogvar = dz*eps*0.5*exp(0.5 logvar) + dlv_ext
  *       + kl_scale*0.5*(exp(logvar)-1).  dz, eps_in, dmu_ext, dlv_ext may be NULL.
  * dcat_bf16 (optional) = [row][dmu(0:L) | dlogvar(L:2L)]. */
@@ -112,6 +121,12 @@ int vae_reparam_kl_bwd(const float* dz, const float* mu, const float* logvar, co
                        const float* dmu_ext, const float* dlv_ext, float kl_scale, float* dmu,
                        float* dlv, void* dcat_bf16, long n_elems, int latent,
                        unsigned long long seed, unsigned step, unsigned rank, void* stream);
+/* The same with dz given as the nsplit split-K slabs [s][n_elems] of the GEMM that produces it (fc_up's input
+ * gradient, vae_linear_gemm_splitk with out == NULL), added here in slab order; nsplit == 0: dz itself. */
+int vae_reparam_kl_bwd_slabs(const float* dz, int nsplit, const float* mu, const float* logvar, const float* eps_in,
+                             const float* dmu_ext, const float* dlv_ext, float kl_scale, float* dmu, float* dlv,
+                             void* dcat_bf16, long n_elems, int latent, unsigned long long seed, unsigned step,
+                             unsigned rank, void* stream);
 /* raw streams, for RNG parity checks.  mode 0: uint32 words, 1: fp32 normals, 2: uint8 keep-mask
  * with drop probability p_drop (16-bit draws, 8 elements per Philox block; kept iff draw >=
  * vae_dropout_threshold(p) = ceil(p * 2^16)).  (torch.randn_like vae.py:110 / nn.Dropout vae.py:137) */
@@ -165,7 +180,8 @@ int vae_linear_gemm(const void* a, const void* w, const float* bias, void* out, 
                     void* stream);
 /* The same nn.Linear forward / dgrad (vae/models/vae.py:96-97,116) for the fp32 epilogues when M
  * is only the batch: the K range is cut into nsplit slabs [nsplit][M][N] (fp32, caller-provided)
- * computed by separate workgroups and summed, with the bias, in a fixed order.
+ * computed by separate workgroups and summed, with the bias, in a fixed order.  out == NULL: the slabs are left
+ * for the caller's next kernel to add up (vae_reparam_kl_fwd_slabs / vae_reparam_kl_bwd_slabs).
  * vae_linear_splitk suggests nsplit (1 = not worth splitting). */
 int vae_linear_splitk(int M, int N, int K);
 int vae_linear_gemm_splitk(const void* a, const void* w, const float* bias, float* out, float* out2,

@@ -64,3 +64,60 @@ def test_linear_splitk_rejects_bad_arguments(L):
     with pytest.raises(RuntimeError, match="empty splits"):     # 4 K-steps cannot be cut into 3 non-empty equal runs
         L.call("vae_linear_gemm_splitk", L.ptr(big), L.ptr(big), None, L.ptr(big), None, L.ptr(big), 3, 64, 64, 256,
                EPI_F32, L.current_stream())
+
+
+def test_reparam_kernels_add_up_the_splitk_slabs_themselves(L):
+    """fc_mu | fc_logvar (vae/models/vae.py:96-97) -> reparameterize (vae.py:108-111), and fc_up's input gradient ->
+    its backward: with out == NULL the split-K GEMM leaves its slabs and the reparameterisation kernel adds them up
+    (bias first, slabs in order) -- bit-identical to the GEMM's own finishing step followed by the plain kernel."""
+    g = torch.Generator().manual_seed(5)
+    M, Lz, K = 96, 128, 4096
+    a = bf(torch.randn(M, K, generator=g)).to(torch.bfloat16).to(DEV)
+    w = bf(torch.randn(2 * Lz, K, generator=g) / K ** 0.5).to(torch.bfloat16).to(DEV)
+    b = torch.randn(2 * Lz, generator=g).to(DEV)
+    ns = L.call("vae_linear_splitk", M, 2 * Lz, K)
+    assert ns > 1
+    n = M * Lz
+    grid = L.call("vae_reparam_grid", n)
+    s = L.current_stream()
+
+    def outs():
+        return [torch.full((M, Lz), float("nan"), device=DEV) for _ in range(3)] + \
+               [torch.zeros(M, Lz, device=DEV, dtype=torch.bfloat16), torch.full((grid,), float("nan"), device=DEV)]
+    # separate: GEMM + finish, then the plain kernel
+    mu1, lv1, z1, zb1, kl1 = outs()
+    slab = torch.full((ns, M, 2 * Lz), float("nan"), device=DEV)
+    L.call("vae_linear_gemm_splitk", L.ptr(a), L.ptr(w), L.ptr(b), L.ptr(mu1), L.ptr(lv1), L.ptr(slab), ns, M, 2 * Lz, K,
+           EPI_F32_SPLIT, s)
+    L.call("vae_reparam_kl_fwd", L.ptr(mu1), L.ptr(lv1), None, L.ptr(z1), L.ptr(zb1), None, L.ptr(kl1), n, 77, 3, 1, s)
+    # fused: GEMM leaves the slabs
+    mu2, lv2, z2, zb2, kl2 = outs()
+    slab2 = torch.full((ns, M, 2 * Lz), float("nan"), device=DEV)
+    L.call("vae_linear_gemm_splitk", L.ptr(a), L.ptr(w), L.ptr(b), None, None, L.ptr(slab2), ns, M, 2 * Lz, K, EPI_F32_SPLIT, s)
+    L.call("vae_reparam_kl_fwd_slabs", L.ptr(slab2), ns, L.ptr(b), L.ptr(mu2), L.ptr(lv2), None, L.ptr(z2), L.ptr(zb2), None,
+           L.ptr(kl2), n, Lz, 77, 3, 1, s)
+    assert torch.equal(slab, slab2)
+    for x1, x2 in ((mu1, mu2), (lv1, lv2), (z1, z2), (zb1, zb2), (kl1, kl2)):
+        assert torch.equal(x1, x2)
+    assert rel_l2(mu1.cpu(), (a.float() @ w.float().t() + b).cpu()[:, :Lz]) <= 1e-5
+
+    # backward: d z = dpre @ W as slabs
+    dpre = bf(torch.randn(M, K, generator=g)).to(torch.bfloat16).to(DEV)
+    wu = bf(torch.randn(Lz, K, generator=g) / K ** 0.5).to(torch.bfloat16).to(DEV)
+    nz = L.call("vae_linear_splitk", M, Lz, K)
+    assert nz > 1
+    dz = torch.full((M, Lz), float("nan"), device=DEV)
+    sl = torch.full((nz, M, Lz), float("nan"), device=DEV)
+    L.call("vae_linear_gemm_splitk", L.ptr(dpre), L.ptr(wu), None, L.ptr(dz), None, L.ptr(sl), nz, M, Lz, K, EPI_F32, s)
+    res = []
+    for fused in (False, True):
+        dmu, dlv = torch.full((M, Lz), float("nan"), device=DEV), torch.full((M, Lz), float("nan"), device=DEV)
+        dcat = torch.zeros(M, 2 * Lz, device=DEV, dtype=torch.bfloat16)
+        L.call("vae_reparam_kl_bwd_slabs", L.ptr(sl) if fused else L.ptr(dz), nz if fused else 0, L.ptr(mu1), L.ptr(lv1), None,
+               None, None, 0.01, L.ptr(dmu), L.ptr(dlv), L.ptr(dcat), n, Lz, 77, 3, 1, s)
+        res.append((dmu, dlv, dcat))
+    for x1, x2 in zip(*res):
+        assert torch.equal(x1, x2)
+    with pytest.raises(RuntimeError, match="slabs need dz"):
+        L.call("vae_reparam_kl_bwd_slabs", None, 2, L.ptr(mu1), L.ptr(lv1), None, None, None, 0.01, L.ptr(dmu), L.ptr(dlv),
+               L.ptr(dcat), n, Lz, 77, 3, 1, s)

@@ -30,6 +30,9 @@ SIGNATURES = {
     "vae_elbo_combine": (None, [P, c_int, P, c_int, c_float, c_float, P, P]),
     "vae_reparam_grid": (c_int, [c_long]),
     "vae_reparam_kl_fwd": (None, [P, P, P, P, P, P, P, c_long, c_ulonglong, c_uint, c_uint, P]),
+    "vae_reparam_kl_fwd_slabs": (None, [P, c_int, P, P, P, P, P, P, P, P, c_long, c_int, c_ulonglong, c_uint, c_uint, P]),
+    "vae_reparam_kl_bwd_slabs": (None, [P, c_int, P, P, P, P, P, c_float, P, P, P, c_long, c_int, c_ulonglong, c_uint,
+                                        c_uint, P]),
     "vae_reparam_kl_bwd": (None, [P, P, P, P, P, P, c_float, P, P, P, c_long, c_int, c_ulonglong,
                                   c_uint, c_uint, P]),
     "vae_philox_fill": (None, [P, c_long, c_int, c_double, c_ulonglong, c_uint, c_uint, c_uint, P]),

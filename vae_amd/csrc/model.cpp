@@ -15,7 +15,7 @@
 
 #include "model_layout.h"
 
-namespace vae { extern int g_conv1_bwd_mode; extern int g_pool_ymax_mode; int g_fold_defer_mode = 0; }
+namespace vae { extern int g_conv1_bwd_mode; extern int g_pool_ymax_mode; int g_fold_defer_mode = 0; int g_slab_reparam_mode = 0; }
 
 namespace {
 using namespace vae_model;
@@ -201,11 +201,19 @@ int bn_finalize(const Ctx& c, int bi, int g_idx, int rows, int fold, double coun
 }
 
 // nn.Linear with an fp32 output and M = batch rows: split-K through the (idle) wgrad slab when that fills the chip
+// *slabs_left (optional): when the GEMM is split over K, its slabs (c.ws.slab2) are left for the caller's next kernel to
+// add up and *slabs_left is their number; 0: out (/ out2) are written here
 int linear_f32(const Ctx& c, const void* a, const void* wgt, const float* bias, float* out, float* out2, int M, int N, int K,
-               int epilogue) {
+               int epilogue, int* slabs_left = nullptr) {
+    if (slabs_left) *slabs_left = 0;
     const int ns = vae_linear_splitk(M, N, K);
-    if (ns > 1 && (long)ns * M * N <= c.ws.slab2_floats)
+    if (ns > 1 && (long)ns * M * N <= c.ws.slab2_floats) {
+        if (slabs_left && vae::g_slab_reparam_mode == 0) {
+            *slabs_left = ns;
+            return vae_linear_gemm_splitk(a, wgt, bias, nullptr, nullptr, (float*)c.at(c.ws.slab2), ns, M, N, K, epilogue, c.stream);
+        }
         return vae_linear_gemm_splitk(a, wgt, bias, out, out2, (float*)c.at(c.ws.slab2), ns, M, N, K, epilogue, c.stream);
+    }
     return vae_linear_gemm(a, wgt, bias, out, out2, nullptr, nullptr, M, N, K, epilogue, c.stream);
 }
 
@@ -300,7 +308,8 @@ static int decoder_forward(const Ctx& c, float* recon) {
                         d.Cout, c.stream);
 }
 
-static int encoder_forward(const Ctx& c, const float* x, const void* const* masks, float* mu, float* logvar, int nbn) {
+static int encoder_forward(const Ctx& c, const float* x, const void* const* masks, float* mu, float* logvar, int nbn,
+                           int* slabs_left = nullptr) {
     const Dims& d = c.d;
     const WsLayout& w = c.ws;
     const int train = c.cfg->train;
@@ -334,7 +343,7 @@ static int encoder_forward(const Ctx& c, const float* x, const void* const* mask
         in = c.at(w.ob[b]);
     }
     return linear_f32(c, in, c.pk_at(c.pk.fc_f), (const float*)c.pk_at(c.pk.bcat), mu, logvar, d.N, 2 * d.L, d.F,
-                      VAE_EPI_F32_SPLIT);
+                      VAE_EPI_F32_SPLIT, slabs_left);
 }
 
 extern "C" int vae_model_forward(const vae_model_cfg* cfg, const float* params, float* bn_stats, const void* wpack,
@@ -348,9 +357,15 @@ extern "C" int vae_model_forward(const vae_model_cfg* cfg, const float* params, 
     }
     CHECK(params && bn_stats && wpack && workspace && x && recon && mu && logvar, "vae_model_forward: null pointer");
     c.params = (float*)params; c.bn = bn_stats; c.wpack = (char*)wpack; c.w = (char*)workspace; c.stream = stream;
-    TRY(encoder_forward(c, x, keep_masks, mu, logvar, 11));
-    TRY(vae_reparam_kl_fwd(mu, logvar, eps_in, nullptr, c.at(c.ws.zb), nullptr, (float*)c.at(c.ws.klp),
-                           (long)c.d.N * c.d.L, cfg->seed, cfg->step, cfg->rank, stream));
+    int ns = 0;      // split-K slabs of the fc_mu | fc_logvar GEMM that the reparameterisation kernel adds up itself
+    TRY(encoder_forward(c, x, keep_masks, mu, logvar, 11, &ns));
+    if (ns > 0)
+        TRY(vae_reparam_kl_fwd_slabs((const float*)c.at(c.ws.slab2), ns, (const float*)c.pk_at(c.pk.bcat), mu, logvar, eps_in,
+                                     nullptr, c.at(c.ws.zb), nullptr, (float*)c.at(c.ws.klp), (long)c.d.N * c.d.L, c.d.L,
+                                     cfg->seed, cfg->step, cfg->rank, stream));
+    else
+        TRY(vae_reparam_kl_fwd(mu, logvar, eps_in, nullptr, c.at(c.ws.zb), nullptr, (float*)c.at(c.ws.klp),
+                               (long)c.d.N * c.d.L, cfg->seed, cfg->step, cfg->rank, stream));
     return decoder_forward(c, recon);
 }
 
@@ -565,8 +580,9 @@ static int backward_decoder(const Ctx& c, Fork* f, const float* d_recon, const f
     TRY(wgrad_to(c, f, &slab, c.at(w.dpre), c.at(w.zb), d.F, d.L, d.N, d.F, d.L, VAE_WGRAD_PLAIN, 1, 1, 1, &ns, sd));
     // slab [(p, c)][l] -> fc_up.weight [(c, p)][l]
     TRY(fold_later(f, slab, ns, (long)d.F * d.L, 0, c.G(P_FC_UP_W), d.hw, 256, d.L, 1, d.L, (long)d.hw * d.L, 1, 0));
-    TRY(linear_f32(c, c.at(w.dpre), c.pk_at(c.pk.up_d), nullptr, (float*)c.at(w.dz), nullptr, d.N, d.L, d.F, VAE_EPI_F32));
-    TRY(vae_reparam_kl_bwd((const float*)c.at(w.dz), mu, logvar, eps_in, dmu_ext, dlv_ext, kl_scale, (float*)c.at(w.dmu),
+    int nsz = 0;     // split-K slabs of d z that the reparameterisation backward adds up itself
+    TRY(linear_f32(c, c.at(w.dpre), c.pk_at(c.pk.up_d), nullptr, (float*)c.at(w.dz), nullptr, d.N, d.L, d.F, VAE_EPI_F32, &nsz));
+    TRY(vae_reparam_kl_bwd_slabs(nsz > 0 ? (const float*)c.at(w.slab2) : (const float*)c.at(w.dz), nsz, mu, logvar, eps_in, dmu_ext, dlv_ext, kl_scale, (float*)c.at(w.dmu),
                            (float*)c.at(w.dlv), c.at(w.dcat), (long)d.N * d.L, d.L, c.cfg->seed, c.cfg->step, c.cfg->rank,
                            c.stream));
     // fc_mu.bias / fc_logvar.bias gradients: column sums of d mu, d logvar

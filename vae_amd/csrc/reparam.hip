@@ -25,10 +25,15 @@ __device__ __forceinline__ PhiloxKey make_key(unsigned long long seed, unsigned 
     return k;
 }
 
+// SLABS: mu | logvar are not read but formed here from the split-K slabs of the fc_mu | fc_logvar GEMM
+// (slab[s][row][2L], bias[2L]; bias first, then the slabs in order -- the sum the GEMM's own finishing kernel forms)
+// and written out: one dependent launch fewer between the encoder and the decoder.
+template <bool SLABS>
 __global__ __launch_bounds__(256) void reparam_kl_fwd_kernel(
-    const float* __restrict__ mu, const float* __restrict__ logvar, const float* __restrict__ eps_in,
+    float* __restrict__ mu, float* __restrict__ logvar, const float* __restrict__ eps_in,
     float* __restrict__ z_f32, bf16_t* __restrict__ z_bf16, float* __restrict__ eps_out,
-    float* __restrict__ kl_partial, long n, unsigned long long seed, unsigned step, unsigned rank) {
+    float* __restrict__ kl_partial, long n, unsigned long long seed, unsigned step, unsigned rank,
+    const float* __restrict__ slab, int nsplit, const float* __restrict__ bias, int L) {
     __shared__ float red[8];
     const PhiloxKey key = make_key(seed, step, VAE_STREAM_EPS, rank);
     const long nblk = (n + 3) >> 2;
@@ -38,7 +43,35 @@ __global__ __launch_bounds__(256) void reparam_kl_fwd_kernel(
         const long i0 = b << 2;
         float m[4], lv[4], e[4], z[4];
         const bool full = i0 + 4 <= n;
-        if (full) {
+        if (SLABS) {           // n is a multiple of L, L of 4: whole float4s inside one row
+            const long row = i0 / L;
+            const int col = (int)(i0 - row * L);
+            const long e = row * 2 * L + col, mn = (n / L) * 2 * L;
+            float4 a = *(const float4*)(bias + col), b4 = *(const float4*)(bias + L + col);
+            int s = 0;
+            for (; s + 3 < nsplit; s += 4) {       // four slabs of both halves requested at once, added in slab order
+                float4 u[4], v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    u[i] = *(const float4*)(slab + (long)(s + i) * mn + e);
+                    v[i] = *(const float4*)(slab + (long)(s + i) * mn + e + L);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    a.x += u[i].x; a.y += u[i].y; a.z += u[i].z; a.w += u[i].w;
+                    b4.x += v[i].x; b4.y += v[i].y; b4.z += v[i].z; b4.w += v[i].w;
+                }
+            }
+            for (; s < nsplit; ++s) {
+                const float4 u = *(const float4*)(slab + (long)s * mn + e), v = *(const float4*)(slab + (long)s * mn + e + L);
+                a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+                b4.x += v.x; b4.y += v.y; b4.z += v.z; b4.w += v.w;
+            }
+            *(float4*)(mu + i0) = a;
+            *(float4*)(logvar + i0) = b4;
+            m[0] = a.x; m[1] = a.y; m[2] = a.z; m[3] = a.w;
+            lv[0] = b4.x; lv[1] = b4.y; lv[2] = b4.z; lv[3] = b4.w;
+        } else if (full) {
             const float4 m4 = *(const float4*)(mu + i0);
             const float4 l4 = *(const float4*)(logvar + i0);
             m[0] = m4.x; m[1] = m4.y; m[2] = m4.z; m[3] = m4.w;
@@ -87,7 +120,8 @@ __global__ __launch_bounds__(256) void reparam_kl_bwd_kernel(
     const float* __restrict__ eps_in, const float* __restrict__ dmu_ext,
     const float* __restrict__ dlv_ext, float kl_scale, float* __restrict__ dmu,
     float* __restrict__ dlv, bf16_t* __restrict__ dcat, long n, int L, unsigned long long seed,
-    unsigned step, unsigned rank) {
+    unsigned step, unsigned rank, int nsplit) {
+    // nsplit > 0: dz points at the nsplit split-K slabs ([s][n]) of the GEMM that produces it; they are added here, in order
     const PhiloxKey key = make_key(seed, step, VAE_STREAM_EPS, rank);
     const long nblk = (n + 3) >> 2;
     for (long b = (long)blockIdx.x * blockDim.x + threadIdx.x; b < nblk;
@@ -100,11 +134,29 @@ __global__ __launch_bounds__(256) void reparam_kl_bwd_kernel(
         } else {
             philox_normal4(key, (uint32_t)b, e);
         }
+        float gsum[4] = {0.f, 0.f, 0.f, 0.f};
+        if (dz && nsplit > 0 && i0 + 4 <= n) {       // (n is a multiple of 4 whenever slabs are used: checked on the host)
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            int s = 0;
+            for (; s + 3 < nsplit; s += 4) {
+                float4 u[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) u[i] = *(const float4*)(dz + (long)(s + i) * n + i0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { a.x += u[i].x; a.y += u[i].y; a.z += u[i].z; a.w += u[i].w; }
+            }
+            for (; s < nsplit; ++s) {
+                const float4 u = *(const float4*)(dz + (long)s * n + i0);
+                a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+            }
+            gsum[0] = a.x; gsum[1] = a.y; gsum[2] = a.z; gsum[3] = a.w;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const long i = i0 + j;
             if (i >= n) break;
-            const float g = dz ? dz[i] : 0.f;
+            float g = 0.f;
+            if (dz) g = nsplit > 0 ? gsum[j] : dz[i];
             const float lv = logvar[i];
             const float sd = expf(0.5f * lv);
             float gm = g + kl_scale * mu[i];
@@ -174,10 +226,29 @@ extern "C" int vae_reparam_kl_fwd(const float* mu, const float* logvar, const fl
     VAE_CHECK(n_elems < (1L << 34), "vae_reparam_kl_fwd: n_elems too large for a 32-bit block counter");
     const int grid = vae_reparam_grid(n_elems);
     ProfScope prof("reparam_kl_fwd_kernel", 0.0, n_elems * (8.0 + (eps_in ? 4.0 : 0.0) + (z_f32 ? 4.0 : 0.0) + (z_bf16 ? 2.0 : 0.0) + (eps_out ? 4.0 : 0.0)), (hipStream_t)stream);
-    hipLaunchKernelGGL(reparam_kl_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, mu,
-                       logvar, eps_in, z_f32, (bf16_t*)z_bf16, eps_out, kl_partial, n_elems, seed,
-                       step, rank);
+    hipLaunchKernelGGL(reparam_kl_fwd_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (float*)mu,
+                       (float*)logvar, eps_in, z_f32, (bf16_t*)z_bf16, eps_out, kl_partial, n_elems, seed,
+                       step, rank, (const float*)nullptr, 0, (const float*)nullptr, 0);
     VAE_LAUNCH_CHECK("reparam_kl_fwd_kernel");
+    return 0;
+}
+
+extern "C" int vae_reparam_kl_fwd_slabs(const float* slab, int nsplit, const float* bias, float* mu, float* logvar,
+                                        const float* eps_in, float* z_f32, void* z_bf16, float* eps_out, float* kl_partial,
+                                        long n_elems, int latent, unsigned long long seed, unsigned step, unsigned rank,
+                                        void* stream) {
+    VAE_CHECK(slab && bias && mu && logvar && kl_partial && nsplit >= 1, "vae_reparam_kl_fwd_slabs: null pointer or no slabs");
+    VAE_CHECK(n_elems > 0 && latent > 0 && latent % 4 == 0 && n_elems % latent == 0,
+              "vae_reparam_kl_fwd_slabs: n_elems (%ld) must be a positive multiple of latent (%d), latent of 4", n_elems, latent);
+    VAE_CHECK((((uintptr_t)slab | (uintptr_t)bias | (uintptr_t)mu | (uintptr_t)logvar | (uintptr_t)z_f32 | (uintptr_t)eps_out) & 15) == 0 &&
+                  ((uintptr_t)z_bf16 & 7) == 0,
+              "vae_reparam_kl_fwd_slabs: pointers must be 16-byte aligned");
+    VAE_CHECK(n_elems < (1L << 34), "vae_reparam_kl_fwd_slabs: n_elems too large for a 32-bit block counter");
+    const int grid = vae_reparam_grid(n_elems);
+    ProfScope prof("reparam_kl_fwd_kernel", 0.0, n_elems * (8.0 * (nsplit + 1) + (eps_in ? 4.0 : 0.0) + (z_f32 ? 4.0 : 0.0) + (z_bf16 ? 2.0 : 0.0) + (eps_out ? 4.0 : 0.0)), (hipStream_t)stream);
+    hipLaunchKernelGGL(reparam_kl_fwd_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, mu, logvar, eps_in, z_f32,
+                       (bf16_t*)z_bf16, eps_out, kl_partial, n_elems, seed, step, rank, slab, nsplit, bias, latent);
+    VAE_LAUNCH_CHECK("reparam_kl_fwd_kernel<slabs>");
     return 0;
 }
 
@@ -186,14 +257,25 @@ extern "C" int vae_reparam_kl_bwd(const float* dz, const float* mu, const float*
                                   float kl_scale, float* dmu, float* dlv, void* dcat_bf16,
                                   long n_elems, int latent, unsigned long long seed, unsigned step,
                                   unsigned rank, void* stream) {
+    return vae_reparam_kl_bwd_slabs(dz, 0, mu, logvar, eps_in, dmu_ext, dlv_ext, kl_scale, dmu, dlv, dcat_bf16, n_elems, latent,
+                                    seed, step, rank, stream);
+}
+
+extern "C" int vae_reparam_kl_bwd_slabs(const float* dz, int nsplit, const float* mu, const float* logvar,
+                                        const float* eps_in, const float* dmu_ext, const float* dlv_ext,
+                                        float kl_scale, float* dmu, float* dlv, void* dcat_bf16,
+                                        long n_elems, int latent, unsigned long long seed, unsigned step,
+                                        unsigned rank, void* stream) {
     VAE_CHECK(mu && logvar, "vae_reparam_kl_bwd: null pointer");
+    VAE_CHECK(nsplit >= 0 && (nsplit == 0 || dz), "vae_reparam_kl_bwd_slabs: nsplit=%d slabs need dz", nsplit);
+    VAE_CHECK(nsplit == 0 || (n_elems % 4 == 0 && ((uintptr_t)dz & 15) == 0), "vae_reparam_kl_bwd_slabs: slabs need n_elems a multiple of 4 and 16-byte alignment");
     VAE_CHECK(n_elems > 0 && latent > 0 && n_elems % latent == 0,
               "vae_reparam_kl_bwd: n_elems (%ld) must be a positive multiple of latent (%d)",
               n_elems, latent);
     const int grid = vae_reparam_grid(n_elems);
     hipLaunchKernelGGL(reparam_kl_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dz, mu,
                        logvar, eps_in, dmu_ext, dlv_ext, kl_scale, dmu, dlv, (bf16_t*)dcat_bf16,
-                       n_elems, latent, seed, step, rank);
+                       n_elems, latent, seed, step, rank, nsplit);
     VAE_LAUNCH_CHECK("reparam_kl_bwd_kernel");
     return 0;
 }
