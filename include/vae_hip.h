@@ -166,10 +166,11 @@ int vae_conv3x3_c8_stat_rows(int n_img, int H, int W, int Cout);
 int vae_convt2x2_fwd_gemm(const void* x, const void* w_packed, const float* bias, void* y,
                           float* stat_sum, float* stat_sq, int n_img, int H, int W, int Cin,
                           int Cout, void* stream);
-/* partial-statistics rows it writes (of 4*Cout floats each; a row may hold the sum over several taps in the columns of
- * the first of them and zeros in the others -- the BatchNorm that follows adds the four taps of a channel anyway);
- * never more than vae_gemm_stat_rows(n*H*W, 4*Cout) */
+/* partial-statistics rows it writes, of vae_convt2x2_stat_fold() * Cout floats each: `fold` column groups of Cout that the
+ * BatchNorm behind it adds up (vae_bn_finalize's `fold`) -- 4, one per tap, unless a workgroup has summed taps itself
+ * (then 2 or 1).  Rows: never more than vae_gemm_stat_rows(n*H*W, 4*Cout). */
 int vae_convt2x2_stat_rows(int n_img, int H, int W, int Cin, int Cout);
+int vae_convt2x2_stat_fold(int n_img, int H, int W, int Cin, int Cout);
 /* its dgrad: dy [n,2H,2W,Cout], w_packed [Cin][(kh,kw,co)], dx [n,H,W,Cin] */
 int vae_convt2x2_dgrad_gemm(const void* dy, const void* w_packed, void* dx, int n_img, int H,
                             int W, int Cin, int Cout, void* stream);

@@ -40,6 +40,7 @@ int stream_c8_launch(const void* x8, const void* w_packed, const float* bias, vo
                      int n_img, int H, int W, int Cout, double flops, double bytes, hipStream_t s);
 bool stream_convt_fwd_ok(int n_img, int H, int W, int Cin, int Cout);
 int stream_convt_fwd_rows(int n_img, int H, int W, int Cin, int Cout);
+int stream_convt_fwd_fold(int Cin, int Cout);
 int stream_convt_fwd_launch(const void* x, const void* w_packed, const float* bias, void* y, float* stat_sum, float* stat_sq,
                             int n_img, int H, int W, int Cin, int Cout, double flops, double bytes, hipStream_t s);
 
@@ -481,6 +482,11 @@ extern "C" int vae_conv3x3_c8_stat_rows(int n_img, int H, int W, int Cout) {
 extern "C" int vae_convt2x2_stat_rows(int n_img, int H, int W, int Cin, int Cout) {
     if (stream_convt_fwd_ok(n_img, H, W, Cin, Cout)) return stream_convt_fwd_rows(n_img, H, W, Cin, Cout);
     return vae_gemm_stat_rows((long)n_img * H * W, 4 * Cout);
+}
+
+extern "C" int vae_convt2x2_stat_fold(int n_img, int H, int W, int Cin, int Cout) {
+    if (stream_convt_fwd_ok(n_img, H, W, Cin, Cout)) return stream_convt_fwd_fold(Cin, Cout);
+    return 4;
 }
 
 extern "C" int vae_conv3x3_stat_rows(int n_img, int H, int W, int Cin, int Cout) {

@@ -297,7 +297,8 @@ static int decoder_forward(const Ctx& c, float* recon) {
         float* sq = train ? (float*)c.at(w.stat_sq) : nullptr;
         TRY(vae_convt2x2_fwd_gemm(in, c.pk_at(c.pk.ct_f[u]), c.P(P_UP3_B + 4 * u), c.at(w.yd[u]), ss, sq, d.N, hh, hh,
                                   DEC_CI[u], DEC_CO[u], c.stream));
-        TRY(bn_finalize(c, 8 + u, P_BN3_G + 4 * u, vae_convt2x2_stat_rows(d.N, hh, hh, DEC_CI[u], DEC_CO[u]), 4, 4.0 * (double)Min));
+        TRY(bn_finalize(c, 8 + u, P_BN3_G + 4 * u, vae_convt2x2_stat_rows(d.N, hh, hh, DEC_CI[u], DEC_CO[u]),
+                        vae_convt2x2_stat_fold(d.N, hh, hh, DEC_CI[u], DEC_CO[u]), 4.0 * (double)Min));
         if (u < 2) {
             TRY(vae_bn_act_fwd(c.at(w.yd[u]), c.coef(8 + u, 0), c.coef(8 + u, 1), c.at(w.ad[u]), d.N, 2 * hh, 2 * hh,
                                DEC_CO[u], 0, 0.0, nullptr, 0, 0, 0, 0, c.stream));

@@ -33,7 +33,7 @@ struct StreamGemm {
     const bf16_t* Wt;     // [N][ldw], K contiguous
     const float* bias;    // [N] ([Co] for SE_CONVT), may be null
     bf16_t* out;
-    float* stat_sum;      // [gridDim.x][N], may be null
+    float* stat_sum;      // [gridDim.x][N / NCH], may be null
     float* stat_sq;
     int M, N;
     int ldw, lda, ldo;
@@ -236,10 +236,9 @@ __global__ __launch_bounds__(256, 3) void stream_gemm_kernel(const StreamGemm p)
         if (tid < 128) {
             const int which = tid >> 6, c = tid & 63;
             const float s = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
+            // the NCH chunks of this workgroup are folded into one: a row has N / NCH columns, 64 per workgroup along y
             float* dst = which ? p.stat_sq : p.stat_sum;
-            dst[(long)blockIdx.x * p.N + n0 + c] = s;
-#pragma unroll
-            for (int q = 1; q < NCH; ++q) dst[(long)blockIdx.x * p.N + n0 + q * 64 + c] = 0.f;   // chunks fold into the first
+            dst[(long)blockIdx.x * (p.N / NCH) + blockIdx.y * 64 + c] = s;
         }
     }
 }
@@ -307,6 +306,8 @@ bool stream_convt_fwd_ok(int n_img, int H, int W, int Cin, int Cout) {
            Cout % 64 == 0 && ((long)n_img * H * W) % 32 == 0 && out_bytes < (1L << 32) &&
            (g_stream_gemm_mode == 2 || (out_bytes >= (48L << 20) && Cout == 64 && Cin <= 128));
 }
+// column groups of Cout in a statistics row (the taps a workgroup does not fold itself)
+int stream_convt_fwd_fold(int Cin, int Cout) { return 4 / convt_fwd_nch(Cin, Cout); }
 int stream_convt_fwd_rows(int n_img, int H, int W, int Cin, int Cout) {
     const int nch = convt_fwd_nch(Cin, Cout);
     return stream_grid_x((long)n_img * H * W, nch * 4 * (Cin / 32) * 1024);
