@@ -374,3 +374,21 @@ def test_tanh_bwd_and_sum_partials(L):
     out = torch.empty(cols, device=DEV)
     L.call("vae_sum_partials", L.ptr(colp), nr, cols, L.ptr(out), 1.0, L.current_stream())
     assert rel_l2(out.cpu(), ref.sum(0)) <= 1e-5
+
+
+def test_layout_conversion_bumps_the_batch_counters(L):
+    """nn.BatchNorm2d adds 1 to num_batches_tracked in every train-mode forward (torch; vae/models/vae.py:26,32): the
+    first kernel of a pass can do it for the layers the pass runs (cfg.batches_tracked of the whole-model entry points)."""
+    g = torch.Generator().manual_seed(9)
+    n, C, H, W = 3, 3, 8, 8
+    x = torch.rand(n, C, H, W, generator=g).to(DEV)
+    a = torch.full((n, H, W, 8), float("nan"), device=DEV, dtype=torch.bfloat16)
+    b = torch.full_like(a, float("nan"))
+    counters = torch.arange(11, device=DEV, dtype=torch.int64)
+    L.call("vae_nchw_to_nhwc8", L.ptr(x), L.ptr(a), n, C, H, W, L.current_stream())
+    L.call("vae_nchw_to_nhwc8_count", L.ptr(x), L.ptr(b), n, C, H, W, L.ptr(counters), 8, L.current_stream())
+    assert torch.equal(a, b)
+    assert torch.equal(a[..., :3].float().cpu(), x.permute(0, 2, 3, 1).to(torch.bfloat16).float().cpu()) and float(a[..., 3:].abs().max()) == 0
+    assert counters.tolist() == [1, 2, 3, 4, 5, 6, 7, 8, 8, 9, 10]
+    L.call("vae_nchw_to_nhwc8_count", L.ptr(x), L.ptr(b), n, C, H, W, None, 0, L.current_stream())
+    assert counters.tolist() == [1, 2, 3, 4, 5, 6, 7, 8, 8, 9, 10]
