@@ -66,7 +66,7 @@ int vae_prof_stop(char* names, int* launches, double* total_ms, double* flops, d
  * re-read the windows; "head_sums" = 0 vae_head_bwd forms its per-channel sums on the matrix pipe (default), 1 in vector registers; "fold_defer" = 0
  * vae_model_backward(stage = -1) folds every split-K slab in one launch at its end (default), 1 in one launch per stage;
  * "slab_reparam" = 0 the whole-model passes let the reparameterisation kernels add up the split-K slabs of the latent GEMMs
- * (default), 1 a finishing kernel does.  Not thread-safe: set it while nothing is being
+ * (default), 1 a finishing kernel does; "convt_bwd" = 0 the 64 -> 64 ConvTranspose backward as one kernel (default), 1 as two.  Not thread-safe: set it while nothing is being
  * launched. */
 int vae_set_tuning(const char* key, int value);
 /* Diagnostic aid: device buffer (>= 128 bytes per workgroup of the launch under study) that the diagnostic kernel
@@ -174,6 +174,15 @@ int vae_convt2x2_stat_fold(int n_img, int H, int W, int Cin, int Cout);
 /* its dgrad: dy [n,2H,2W,Cout], w_packed [Cin][(kh,kw,co)], dx [n,H,W,Cin] */
 int vae_convt2x2_dgrad_gemm(const void* dy, const void* w_packed, void* dx, int n_img, int H,
                             int W, int Cin, int Cout, void* stream);
+/* Input gradient AND weight gradient of a 64 -> 64 ConvTranspose2d(k2, s2) (vae/models/vae.py:131 with the default widths) in
+ * one kernel that reads dy once: dx as vae_convt2x2_dgrad_gemm, the weight gradient as vae_wgrad_gemm(VAE_WGRAD_CONVT) --
+ * vae_convt2x2_bwd_fused_slabs(n, H, W) split-K slabs [slab][co][tap][ci] of 4*64*64 floats, to be folded the same way.
+ * dy [n,2H,2W,64], x [n,H,W,64] bf16; w_packed: the operand of vae_convt2x2_dgrad_gemm.  n*H*W must be a multiple of 64;
+ * vae_convt2x2_bwd_fused_ok says whether the geometry is covered (and the "convt_bwd" tuning key leaves it on). */
+int vae_convt2x2_bwd_fused_ok(int n_img, int H, int W, int Cin, int Cout);
+int vae_convt2x2_bwd_fused_slabs(int n_img, int H, int W);
+int vae_convt2x2_bwd_fused(const void* dy, const void* x, const void* w_packed, void* dx, float* slab, int n_img,
+                           int H, int W, int Cin, int Cout, void* stream);
 /* nn.Linear forward / dgrad (fc_mu | fc_logvar fused, fc_up), vae/models/vae.py:48-49,63,96-97,116:
  * out[m][n] = sum_k a[m][k] w[n][k] (+ bias[n]).  K % 64 == 0, or K % 32 == 0 with VAE_EPI_BF16. */
 int vae_linear_gemm(const void* a, const void* w, const float* bias, void* out, void* out2,

@@ -114,3 +114,40 @@ def test_convt2x2_streaming_fwd(L, n, H, W, Ci, Co):
         outs[mode] = (y.float().cpu(), dx.float().cpu())
     L.call("vae_set_tuning", b"stream_gemm", 0)
     assert rel_l2(outs[2][0], outs[1][0]) <= 1e-3 and torch.equal(outs[2][1], outs[1][1])
+
+
+@pytest.mark.parametrize("n,H,W", [(2, 8, 8), (16, 16, 16), (3, 4, 16), (1, 8, 8), (40, 16, 16)])
+def test_convt_backward_in_one_kernel(L, n, H, W):
+    """ConvTranspose2d(64, 64, 2, 2) backward (vae/models/vae.py:131): input gradient and weight gradient from one read of
+    dY, against torch autograd on the bf16-rounded operands and against the two separate kernels.  Sizes: one tile, many
+    tiles per workgroup (40 * 256 pixels = 160 tiles... on up to 256 workgroups), a non-square grid."""
+    Ci = Co = 64
+    assert L.call("vae_convt2x2_bwd_fused_ok", n, H, W, Ci, Co) == 1
+    assert L.call("vae_convt2x2_bwd_fused_ok", n, H, W, 128, 64) == 0
+    g = torch.Generator().manual_seed(n * 100 + H)
+    x = bf(torch.randn(n, Ci, H, W, generator=g))
+    w = bf(torch.randn(Ci, Co, 2, 2, generator=g) / Ci ** 0.5)
+    dy = bf(torch.randn(n, Co, 2 * H, 2 * W, generator=g))
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    F.conv_transpose2d(xr, wr, None, stride=2).backward(dy)
+    wd = w.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV)      # [ci][(kh,kw,co)]
+    xd, dyd = nhwc(x), nhwc(dy)
+    ns = L.call("vae_convt2x2_bwd_fused_slabs", n, H, W)
+    assert 1 <= ns <= 256
+    dx = torch.full((n, H, W, Ci), float("nan"), device=DEV, dtype=torch.bfloat16)
+    slab = torch.full((ns, Co, 4, Ci), float("nan"), device=DEV)
+    L.call("vae_convt2x2_bwd_fused", L.ptr(dyd), L.ptr(xd), L.ptr(wd), L.ptr(dx), L.ptr(slab), n, H, W, Ci, Co, L.current_stream())
+    check_bf16(from_nhwc(dx), xr.grad, "fused convT dgrad")
+    dw = slab.sum(0).permute(2, 0, 1).reshape(Ci, Co, 2, 2).cpu()          # [co][tap][ci] -> [ci][co][kh][kw]
+    assert rel_l2(dw, wr.grad) <= 1e-5
+    # the separate kernels
+    dx2 = torch.full_like(dx, float("nan"))
+    L.call("vae_convt2x2_dgrad_gemm", L.ptr(dyd), L.ptr(wd), L.ptr(dx2), n, H, W, Ci, Co, L.current_stream())
+    assert rel_l2(dx.float().cpu(), dx2.float().cpu()) <= 1e-3
+    M = n * H * W
+    ns2 = L.call("vae_wgrad_ksplit", Co, Ci, 4, M)
+    slab2 = torch.full((ns2, Co, 4, Ci), float("nan"), device=DEV)
+    L.call("vae_wgrad_gemm", L.ptr(dyd), L.ptr(xd), L.ptr(slab2), Co, Ci, M, Co, Ci, 2, H, W, ns2, L.current_stream())
+    assert rel_l2(slab.sum(0).cpu(), slab2.sum(0).cpu()) <= 1e-5
+    with pytest.raises(RuntimeError, match="64 -> 64 channels only"):
+        L.call("vae_convt2x2_bwd_fused", L.ptr(dyd), L.ptr(xd), L.ptr(wd), L.ptr(dx), L.ptr(slab), n, H, W, 128, 64, L.current_stream())

@@ -42,6 +42,9 @@ SIGNATURES = {
     "vae_conv3x3_c8_stat_rows": (c_int, [c_int, c_int, c_int, c_int]),
     "vae_convt2x2_stat_rows": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "vae_convt2x2_stat_fold": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "vae_convt2x2_bwd_fused_ok": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "vae_convt2x2_bwd_fused_slabs": (c_int, [c_int, c_int, c_int]),
+    "vae_convt2x2_bwd_fused": (None, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "vae_conv3x3_stat_rows": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "vae_conv3x3_gemm": (None, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "vae_convt2x2_fwd_gemm": (None, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),

@@ -68,6 +68,7 @@ extern int g_pool_ymax_mode;
 extern int g_head_sums_mode;
 extern int g_fold_defer_mode;
 extern int g_slab_reparam_mode;
+extern int g_convt_bwd_mode;
 extern unsigned long long* g_conv3_dbg;
 }
 // Diagnostic aid: a device buffer that diagnostic kernel variants write cycle stamps to (null = none).
@@ -111,6 +112,10 @@ extern "C" int vae_set_tuning(const char* key, int value) {
     }
     if (key && !strcmp(key, "slab_reparam")) {        // split-K slabs of the latent GEMMs: 0 added up by the reparameterisation kernels, 1 by a finishing kernel
         vae::g_slab_reparam_mode = value;
+        return 0;
+    }
+    if (key && !strcmp(key, "convt_bwd")) {           // 64 -> 64 ConvTranspose backward: 0 one kernel (dY read once), 1 separate input- and weight-gradient kernels
+        vae::g_convt_bwd_mode = value;
         return 0;
     }
     if (key && !strcmp(key, "stream_gemm")) {         // 0 the streaming GEMM where it pays, 1 never (tiled GEMM), 2 wherever legal

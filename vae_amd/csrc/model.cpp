@@ -123,7 +123,12 @@ void make_ws_layout(const Dims& d, WsLayout* w) {
     }
     for (int u = 0; u < 3; ++u) {
         const long hh = (long)s8 << u;
-        s += up64(slab_need(DEC_CO[u], DEC_CI[u], 4, (long)d.N * hh * hh));
+        long v = slab_need(DEC_CO[u], DEC_CI[u], 4, (long)d.N * hh * hh);
+        if (DEC_CO[u] == 64 && DEC_CI[u] == 64) {       // either form of its backward
+            const long vf = (long)vae_convt2x2_bwd_fused_slabs(d.N, (int)hh, (int)hh) * 4 * 64 * 64;
+            if (vf > v) v = vf;
+        }
+        s += up64(v);
     }
     s += up64(slab_need(2 * d.L, d.F, 1, d.N));
     s += up64(slab_need(d.F, d.L, 1, d.N));
@@ -551,6 +556,16 @@ static int backward_decoder(const Ctx& c, Fork* f, const float* d_recon, const f
         const long Min = (long)d.N * hh * hh;
         const int Ci = DEC_CI[u], Co = DEC_CO[u];
         const void* xin = u == 0 ? c.at(w.h) : c.at(w.ad[u - 1]);
+        if (vae_convt2x2_bwd_fused_ok(d.N, hh, hh, Ci, Co)) {
+            // both gradients from one read of dY, on the main stream (there is no separate weight-gradient kernel to move;
+            // the side stream's later waits on the main stream order the fold behind it)
+            const int nsl = vae_convt2x2_bwd_fused_slabs(d.N, hh, hh);
+            TRY(slab_take(c, f, (long)nsl * 4 * Co * Ci, &slab));
+            TRY(main_after(f, w_prev));    // buffer y was read by the previous iteration's wgrad
+            TRY(vae_convt2x2_bwd_fused(c.at(w.g[x]), xin, c.pk_at(c.pk.ct_d[u]), c.at(w.g[y]), slab, d.N, hh, hh, Ci, Co, c.stream));
+            TRY(fold_later(f, slab, nsl, 4L * Co * Ci, 0, c.G(P_UP3_W + 4 * u), Co, 4, Ci, 1, 4, 1, 4L * Co, 0));
+            w_prev = nullptr;
+        } else {
         TRY(side_after_main(f));
         TRY(wgrad_to(c, f, &slab, c.at(w.g[x]), xin, Co, Ci, Min, Co, Ci, VAE_WGRAD_CONVT, hh, hh, 4, &ns, sd));
         // slab [co][tap][ci] -> ConvTranspose2d weight [ci][co][tap]
@@ -561,6 +576,7 @@ static int backward_decoder(const Ctx& c, Fork* f, const float* d_recon, const f
         TRY(main_after(f, w_prev));    // buffer y was read by the previous iteration's wgrad
         TRY(vae_convt2x2_dgrad_gemm(c.at(w.g[x]), c.pk_at(c.pk.ct_d[u]), c.at(w.g[y]), d.N, hh, hh, Ci, Co, c.stream));
         w_prev = w_this;
+        }
         if (u > 0) {
             const int bi = 8 + (u - 1);
             TRY(vae_bn_act_bwd(c.at(w.g[y]), c.at(w.yd[u - 1]), c.coef(bi, 0), c.coef(bi, 1), c.coef(bi, 2), c.coef(bi, 3),
