@@ -66,7 +66,8 @@ int vae_prof_stop(char* names, int* launches, double* total_ms, double* flops, d
  * re-read the windows; "head_sums" = 0 vae_head_bwd forms its per-channel sums on the matrix pipe (default), 1 in vector registers; "fold_defer" = 0
  * vae_model_backward(stage = -1) folds every split-K slab in one launch at its end (default), 1 in one launch per stage;
  * "slab_reparam" = 0 the whole-model passes let the reparameterisation kernels add up the split-K slabs of the latent GEMMs
- * (default), 1 a finishing kernel does; "convt_bwd" = 0 the 64 -> 64 ConvTranspose backward as one kernel (default), 1 as two.  Not thread-safe: set it while nothing is being
+ * (default), 1 a finishing kernel does; "convt_bwd" = 0 the 64 -> 64 ConvTranspose backward as one kernel that also makes the head's gradient
+ * on the way (default), 1 as separate input- and weight-gradient kernels, 2 one kernel reading the stored gradient.  Not thread-safe: set it while nothing is being
  * launched. */
 int vae_set_tuning(const char* key, int value);
 /* Diagnostic aid: device buffer (>= 128 bytes per workgroup of the launch under study) that the diagnostic kernel
@@ -375,6 +376,19 @@ int vae_head_bwd(const float* drecon, const float* recon, const void* y, const f
                  const float* shift, const float* mean, const float* rstd, const float* w,
                  float* partial, float* sums, float* sums_head, void* dy, int n_img, int H, int W,
                  int Cout, void* stream);
+/* The sums of vae_head_bwd alone (sums, sums_head as there; no dy), also leaving the logit gradients
+ * dl [n*H*W][4] f32 = drecon * recon * (1 - recon) (entries >= Cout are 0): the input of vae_head_convt_bwd_fused. */
+int vae_head_bwd_sums(const float* drecon, const float* recon, const void* y, const float* scale,
+                      const float* shift, const float* mean, const float* rstd, const float* w,
+                      float* partial, float* sums, float* sums_head, float* dl, int n_img, int H, int W,
+                      int Cout, void* stream);
+/* vae_head_bwd's second pass and vae_convt2x2_bwd_fused in one kernel (vae/models/vae.py:131-134, the default 64 -> 64
+ * widths): the gradient dy behind bn1 + ReLU + head is computed from y [n,2H,2W,64] (the ConvTranspose output), dl and
+ * the sums of vae_head_bwd_sums, tile by tile in LDS, and never stored; dx [n,H,W,64] and the weight-gradient slabs
+ * come out as from vae_convt2x2_bwd_fused (same slab count).  x [n,H,W,64]: the ConvTranspose input. */
+int vae_head_convt_bwd_fused(const void* y, const float* dl, const float* scale, const float* shift, const float* mean,
+                             const float* rstd, const float* sums, const float* w_head, int Cout_head, const void* x,
+                             const void* w_packed, void* dx, float* slab, int n_img, int H, int W, void* stream);
 /* torch.clamp(x, lo, hi) on fp32 (logvar in the deeper U-Net draft, vae/practice/vae_original.py:390) and its
  * backward: g null -> out = clamp(x); g given -> out = g where lo <= x <= hi, else 0. */
 int vae_clamp_f32(const float* x, const float* g, float lo, float hi, float* out, long n, void* stream);

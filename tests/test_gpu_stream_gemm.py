@@ -151,3 +151,69 @@ def test_convt_backward_in_one_kernel(L, n, H, W):
     assert rel_l2(slab.sum(0).cpu(), slab2.sum(0).cpu()) <= 1e-5
     with pytest.raises(RuntimeError, match="64 -> 64 channels only"):
         L.call("vae_convt2x2_bwd_fused", L.ptr(dyd), L.ptr(xd), L.ptr(wd), L.ptr(dx), L.ptr(slab), n, H, W, 128, 64, L.current_stream())
+
+
+@pytest.mark.parametrize("n,H,W,Co_head", [(2, 8, 8, 3), (24, 16, 16, 3), (1, 8, 8, 1), (3, 4, 16, 4)])
+def test_head_and_convt_backward_without_the_gradient_tensor(L, n, H, W, Co_head):
+    """bn1 + ReLU + 1x1 head backward followed by the last ConvTranspose's backward (vae/models/vae.py:131-134): the pair
+    vae_head_bwd_sums + vae_head_convt_bwd_fused computes the head's gradient tile by tile inside the ConvTranspose kernel
+    and must give what vae_head_bwd (gradient stored as bf16) + vae_convt2x2_bwd_fused give, to the bf16 rounding of that
+    gradient, and what an fp64 evaluation of the formulas gives."""
+    g = torch.Generator().manual_seed(n + H + Co_head)
+    C = 64
+    y = bf(torch.randn(n, 2 * H, 2 * W, C, generator=g) * 1.3 + 0.2).to(torch.bfloat16).to(DEV)      # ConvT output, NHWC
+    x = bf(torch.randn(n, H, W, C, generator=g)).to(torch.bfloat16).to(DEV)
+    wct = bf(torch.randn(C, C, 2, 2, generator=g) / 8)
+    wd = wct.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV)
+    yf = y.float()
+    mean, var = yf.mean((0, 1, 2)), yf.var((0, 1, 2), unbiased=False)
+    rstd = 1 / torch.sqrt(var + 1e-5)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(DEV), (torch.randn(C, generator=g) * 0.2).to(DEV)
+    sc = gamma * rstd
+    sh = beta - mean * sc
+    wh = (torch.randn(Co_head, C, generator=g) * 0.2).to(DEV)
+    recon = torch.rand(n, Co_head, 2 * H, 2 * W, generator=g).to(DEV) * 0.9 + 0.05
+    drecon = torch.randn(n, Co_head, 2 * H, 2 * W, generator=g).to(DEV) * 1e-3
+    s = L.current_stream()
+    nb = L.call("vae_head_bwd_blocks", n, 2 * H, 2 * W)
+    ncols = (3 + Co_head) * 64
+    # stored form
+    part = torch.empty(nb, ncols, device=DEV)
+    sums1, sh1 = torch.empty(128, device=DEV), torch.empty(Co_head * 65, device=DEV)
+    gbuf = torch.full((n, 2 * H, 2 * W, C), float("nan"), device=DEV, dtype=torch.bfloat16)
+    L.call("vae_head_bwd", L.ptr(drecon), L.ptr(recon), L.ptr(y), L.ptr(sc), L.ptr(sh), L.ptr(mean), L.ptr(rstd), L.ptr(wh),
+           L.ptr(part), L.ptr(sums1), L.ptr(sh1), L.ptr(gbuf), n, 2 * H, 2 * W, Co_head, s)
+    ns = L.call("vae_convt2x2_bwd_fused_slabs", n, H, W)
+    dx1 = torch.full((n, H, W, C), float("nan"), device=DEV, dtype=torch.bfloat16)
+    slab1 = torch.full((ns, C, 4, C), float("nan"), device=DEV)
+    L.call("vae_convt2x2_bwd_fused", L.ptr(gbuf), L.ptr(x), L.ptr(wd), L.ptr(dx1), L.ptr(slab1), n, H, W, C, C, s)
+    # on-the-fly form
+    part2 = torch.empty(nb, ncols, device=DEV)
+    sums2, sh2 = torch.empty(128, device=DEV), torch.empty(Co_head * 65, device=DEV)
+    dl = torch.full((n * 4 * H * W, 4), float("nan"), device=DEV)
+    L.call("vae_head_bwd_sums", L.ptr(drecon), L.ptr(recon), L.ptr(y), L.ptr(sc), L.ptr(sh), L.ptr(mean), L.ptr(rstd), L.ptr(wh),
+           L.ptr(part2), L.ptr(sums2), L.ptr(sh2), L.ptr(dl), n, 2 * H, 2 * W, Co_head, s)
+    assert torch.equal(sums1, sums2) and torch.equal(sh1, sh2)
+    dl_ref = (drecon * recon * (1 - recon)).permute(0, 2, 3, 1).reshape(-1, Co_head)
+    assert torch.equal(dl[:, :Co_head], dl_ref) and float(dl[:, Co_head:].abs().max() if Co_head < 4 else 0) == 0
+    dx2 = torch.full_like(dx1, float("nan"))
+    slab2 = torch.full_like(slab1, float("nan"))
+    L.call("vae_head_convt_bwd_fused", L.ptr(y), L.ptr(dl), L.ptr(sc), L.ptr(sh), L.ptr(mean), L.ptr(rstd), L.ptr(sums2), L.ptr(wh),
+           Co_head, L.ptr(x), L.ptr(wd), L.ptr(dx2), L.ptr(slab2), n, H, W, s)
+    # the gradient is formed as one affine expression here and in head_bwd's own order there: bf16 roundings of it differ
+    # in the last bit now and then
+    assert rel_l2(dx2.float().cpu(), dx1.float().cpu()) <= 2e-3
+    assert rel_l2(slab2.sum(0).cpu(), slab1.sum(0).cpu()) <= 2e-3
+    # and against fp64: the head's gradient, then the ConvTranspose's two gradients
+    v = lambda t: t.double().cpu()
+    yd_, dlr = v(yf), v(dl_ref).view(n, 2 * H, 2 * W, Co_head)
+    pos = (yf * sc + sh > 0).cpu()
+    da = torch.einsum("nhwo,oc->nhwc", dlr, v(wh))
+    gg = torch.where(pos, da, torch.zeros((), dtype=torch.float64))
+    xh = (yd_ - v(mean)) * v(rstd)
+    cnt = n * 4 * H * W
+    gref = v(sc) * (gg - gg.sum((0, 1, 2)) / cnt - xh * (gg * xh).sum((0, 1, 2)) / cnt)
+    xr, wr = v(x.float()).permute(0, 3, 1, 2).requires_grad_(True), wct.double().requires_grad_(True)
+    F.conv_transpose2d(xr, wr, None, stride=2).backward(gref.permute(0, 3, 1, 2))
+    assert rel_l2(dx2.float().cpu().permute(0, 3, 1, 2), xr.grad.float()) <= 4e-3          # g rounded to bf16 in LDS, dx to bf16
+    assert rel_l2(slab2.sum(0).permute(2, 0, 1).reshape(C, C, 2, 2).cpu(), wr.grad.float()) <= 4e-3

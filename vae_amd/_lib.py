@@ -93,6 +93,8 @@ SIGNATURES = {
     "vae_head_fwd": (None, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "vae_head_bwd_blocks": (c_int, [c_int, c_int, c_int]),
     "vae_head_bwd": (None, [P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "vae_head_bwd_sums": (None, [P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "vae_head_convt_bwd_fused": (None, [P, P, P, P, P, P, P, P, c_int, P, P, P, P, c_int, c_int, c_int, P]),
     "vae_reduce_slabs_scatter": (None, [P, c_int, c_long, c_long, P, P, P, P, c_long, c_int, P]),
     "vae_multi_pack": (None, [P, c_int, P]),
     "vae_multi_reduce_slabs_scatter": (None, [P, c_int, P]),

@@ -48,6 +48,7 @@ struct Conv1Bwd {
     const float* drecon;
     const float* recon;
     int hw, hwshift;
+    float* dl_out;        // optional: the logit gradients dl [pixel][4] (for the fused backward of the layer in front)
 };
 
 // swizzles of the 16-byte chunk index: the 8 rows {b..b+3, b+8..b+11} one half of a transposing read touches land on
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(256, 3) void bn_bwd_conv1_kernel(const Conv1Bwd p) 
         }
     };
     // the fetched registers -> LDS stage `buf`: d = gin where the ReLU passed (the forward's fp32 predicate), y as it is
-    auto deposit = [&](const InFlight& r, int buf) {
+    auto deposit = [&](const InFlight& r, int buf, int tile) {
         const uint4(&rg)[2] = r.g;
         const uint4(&ry)[2] = r.y;
         const uint2(&rx)[3] = r.x;
@@ -189,13 +190,17 @@ __global__ __launch_bounds__(256, 3) void bn_bwd_conv1_kernel(const Conv1Bwd p) 
         if (MODE == 1) {
             if (tid < C1_BK) {
                 uint32_t hi[4], lo[4];
+                float dlv[4];
 #pragma unroll
                 for (int o = 0; o < 4; ++o) {
                     const float dl = r.hd[o] * r.hr[o] * (1.f - r.hr[o]);
+                    dlv[o] = dl;
                     const bf16_t h16 = f2bf(dl);
                     hi[o] = h16;
                     lo[o] = f2bf(dl - bf2f(h16));
                 }
+                if (p.dl_out && tile * C1_BK + tid < p.npix)
+                    *(float4*)(p.dl_out + ((long)tile * C1_BK + tid) * 4) = make_float4(dlv[0], dlv[1], dlv[2], dlv[3]);
                 *(uint4*)(xbase + tid * C1_ROWX + (c1_swz_x(tid) << 4)) =
                     make_uint4(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
             }
@@ -261,7 +266,7 @@ __global__ __launch_bounds__(256, 3) void bn_bwd_conv1_kernel(const Conv1Bwd p) 
     int tile = blockIdx.x;
     fetch(r0, tile);
     __syncthreads();                       // the clear and the ones column are complete
-    deposit(r0, 0);
+    deposit(r0, 0, tile);
     if (tile + G < p.ntile) fetch(r0, tile + G);
     barrier_keep_copies();
     int buf = 0;
@@ -269,7 +274,7 @@ __global__ __launch_bounds__(256, 3) void bn_bwd_conv1_kernel(const Conv1Bwd p) 
         compute(buf);
         const bool more = tile + G < p.ntile;
         if (more) {
-            deposit(r0, buf ^ 1);
+            deposit(r0, buf ^ 1, tile + G);
             if (tile + 2 * G < p.ntile) fetch(r0, tile + 2 * G);
         }
         barrier_keep_copies();             // stage buf is read out, stage buf ^ 1 is written
@@ -390,8 +395,9 @@ long head_sums_scratch_floats(long npix) { return ((long)c1_blocks(npix) + 1) * 
 // the sums of vae_head_bwd (norm.hip) on the matrix pipe; scratch: head_sums_scratch_floats(npix) floats
 int head_sums_mfma(const float* drecon, const float* recon, const bf16_t* y, const float* scale, const float* shift,
                    const float* mean, const float* rstd, const float* w, float* scratch, float* sums, float* sums_head,
-                   long npix, int hw, int CO, hipStream_t s) {
+                   long npix, int hw, int CO, float* dl_out, hipStream_t s) {
     Conv1Bwd p = {};
+    p.dl_out = dl_out;
     p.y = y; p.scale = scale; p.shift = shift; p.mean = mean; p.rstd = rstd; p.part = scratch;
     p.npix = (int)npix; p.ntile = (int)((npix + C1_BK - 1) / C1_BK);
     p.drecon = drecon; p.recon = recon; p.hw = hw; p.hwshift = c1_shift(hw);

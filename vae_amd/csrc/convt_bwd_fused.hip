@@ -202,6 +202,170 @@ __global__ __launch_bounds__(64 * CB_NW, 1) void convt_bwd_fused_kernel(const Co
                 make_float4(accw[kb][cb][0], accw[kb][cb][1], accw[kb][cb][2], accw[kb][cb][3]);
 }
 
+// The same backward with dY not read but made on the way: dY here is the gradient behind the last BatchNorm + ReLU + 1x1
+// head (vae/models/vae.py:132-134), g = scale * (pos * sum_o w[o][c] dl[o] - mean(g) - xhat * mean(g * xhat)), a function of
+// the ConvTranspose's own output y, of the logit gradients dl (3-4 floats per pixel) and of per-channel constants.  The
+// tile's 256 rows of g are computed from y into LDS instead of copied, so the 67 MB tensor is neither written nor read: y and dl in, dX and the dW slabs out.  Register-staged
+// tiles (the next tile's y is in flight during the matrix work), two LDS stages, eight waves.
+struct HeadConvtBwd {
+    const bf16_t* y;      // [n][2H][2W][64], the ConvTranspose output
+    const float* dl;      // [n * 2H * 2W][4] logit gradients
+    const float* scale;
+    const float* shift;
+    const float* mean;
+    const float* rstd;
+    const float* sums;    // [sum g * xhat (64) | sum g (64)]
+    const float* w;       // head weights [CO][64]
+    float inv_count;
+    const bf16_t* a;
+    const bf16_t* wd;
+    bf16_t* dx;
+    float* slab;
+    int npix, H, W, wshift, hshift, ntile;
+};
+
+template <int CO>
+__global__ __launch_bounds__(64 * CB_NW, 1) void head_convt_bwd_kernel(const HeadConvtBwd p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * CB_STAGE + CB_W];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int wq = wave & 3, wh = wave >> 2;
+    const int px = tid >> 3, cg = tid & 7, c0 = cg * 8;      // staging: this lane's pixel of the tile and its 8 channels
+    unsigned char* const wl = smem + 2 * CB_STAGE;
+#pragma unroll
+    for (int i = 0; i < CB_W / 16 / (64 * CB_NW); ++i) {
+        const int idx = tid + 64 * CB_NW * i, row = idx >> 5, cl = idx & 31;
+        *(uint4*)(wl + row * CB_ROWP + cl * 16) = *(const uint4*)(p.wd + row * 256 + (cl ^ cb_swz_w(row)) * 8);
+    }
+    // g = scale * (pos * da - c1 - xhat * c2) with da = sum_o w[o] dl[o], xhat = (y - mean) * rstd, as one affine form in
+    // y plus the gated term:  g = pos * sum_o (scale w[o]) dl[o] + (ka * y + kb),  ka = -scale c2 rstd,
+    // kb = scale (c2 rstd mean - c1): ten vector operations per element instead of seventeen (the staging of a tile is
+    // bound by them).  The ReLU predicate keeps the forward's own two-rounding form.
+    float sc[8], sh[8], ka[8], kb[8], swv[CO][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        sc[i] = p.scale[c0 + i]; sh[i] = p.shift[c0 + i];
+        const float mu = p.mean[c0 + i], rs = p.rstd[c0 + i];
+        const float c2 = p.sums[c0 + i] * p.inv_count, c1 = p.sums[64 + c0 + i] * p.inv_count;
+        ka[i] = -sc[i] * c2 * rs;
+        kb[i] = sc[i] * (c2 * rs * mu - c1);
+#pragma unroll
+        for (int o = 0; o < CO; ++o) swv[o][i] = sc[i] * p.w[o * 64 + c0 + i];
+    }
+    struct InFlight {
+        uint4 y[4];
+        float4 d[4];
+        uint4 x;
+    };
+    InFlight r0;
+    auto fetch = [&](InFlight& r, int tile) {
+        const int k = tile * CB_BK + px;          // whole tiles: k < npix
+        int h, w, img;
+        if (p.wshift >= 0 && p.hshift >= 0) { w = k & (p.W - 1); h = (k >> p.wshift) & (p.H - 1); img = k >> (p.wshift + p.hshift); }
+        else { w = k % p.W; const int q = k / p.W; h = q % p.H; img = q / p.H; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long rr = ((long)img * 2 * p.H + 2 * h + (j >> 1)) * (2 * p.W) + 2 * w + (j & 1);
+            r.y[j] = *(const uint4*)(p.y + rr * 64 + c0);
+            r.d[j] = *(const float4*)(p.dl + rr * 4);
+        }
+        r.x = *(const uint4*)(p.a + (long)k * 64 + c0);
+    };
+    auto deposit = [&](const InFlight& r, int buf) {
+        unsigned char* pbase = smem + buf * CB_STAGE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t yw[4] = {r.y[j].x, r.y[j].y, r.y[j].z, r.y[j].w};
+            const float dl[4] = {r.d[j].x, r.d[j].y, r.d[j].z, r.d[j].w};
+            float o8[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float v = __uint_as_float((i & 1) ? (yw[i >> 1] & 0xFFFF0000u) : (yw[i >> 1] << 16));
+                const bool pos = v * sc[i] + sh[i] > 0.f;
+                float da = dl[0] * swv[0][i];
+#pragma unroll
+                for (int o = 1; o < CO; ++o) da = fmaf(dl[o], swv[o][i], da);
+                o8[i] = (pos ? da : 0.f) + fmaf(ka[i], v, kb[i]);
+            }
+            *(uint4*)(pbase + px * CB_ROWP + (((j * 8 + cg) ^ cb_swz_p(px)) << 4)) =
+                make_uint4(pack2bf(o8[0], o8[1]), pack2bf(o8[2], o8[3]), pack2bf(o8[4], o8[5]), pack2bf(o8[6], o8[7]));
+        }
+        *(uint4*)(pbase + CB_P + px * CB_ROWQ + ((cg ^ cb_swz_q(px)) << 4)) = r.x;
+    };
+
+    f32x4 accw[4][2];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) accw[kb][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int G = gridDim.x;
+    int tile = blockIdx.x;
+    fetch(r0, tile);
+    deposit(r0, 0);
+    if (tile + G < p.ntile) fetch(r0, tile + G);
+    __syncthreads();                       // the weights and the first tile are in LDS (the prefetch is waited for here too, once)
+    int buf = 0;
+    while (true) {
+        const unsigned char* pb = smem + buf * CB_STAGE;
+        const unsigned pbase = (unsigned)(size_t)(cb_lptr_t)smem + (unsigned)(buf * CB_STAGE), qbase = pbase + CB_P;
+        f32x4 accd[2];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) accd[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int rowd = 16 * wq + l15;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const int c = ks * 4 + g4;
+            const bf16x8 gf = *(const bf16x8*)(pb + rowd * CB_ROWP + ((c ^ cb_swz_p(rowd)) << 4));
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                const int ci = (2 * wh + nb) * 16 + l15;
+                const bf16x8 wf = *(const bf16x8*)(wl + ci * CB_ROWP + ((c ^ cb_swz_w(ci)) << 4));
+                accd[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, gf, accd[nb], 0, 0, 0);
+            }
+        }
+        {
+            bf16_t* dst = p.dx + ((long)tile * CB_BK + rowd) * 64 + 32 * wh + 4 * g4;
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+                *(uint2*)(dst + nb * 16) = make_uint2(pack2bf(accd[nb][0], accd[nb][1]), pack2bf(accd[nb][2], accd[nb][3]));
+        }
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            bf16x8 gt[4], at[2];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) gt[j] = cb_tr_frag<CB_ROWP>(pbase, 32 * ps, wq * 64 + j * 16, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) at[j] = cb_tr_frag<CB_ROWQ>(qbase, 32 * ps, (2 * wh + j) * 16, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cb_wait(gt[j]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) cb_wait(at[j]);
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) accw[kb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at[cb], gt[kb], accw[kb][cb], 0, 0, 0);
+        }
+        const bool more = tile + G < p.ntile;
+        if (more) {
+            deposit(r0, buf ^ 1);
+            if (tile + 2 * G < p.ntile) fetch(r0, tile + 2 * G);
+        }
+        barrier_keep_copies();             // stage buf is read out, stage buf ^ 1 is written
+        if (!more) break;
+        tile += G;
+        buf ^= 1;
+    }
+    float* out = p.slab + (long)blockIdx.x * (4 * 64 * 64);
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+            *(float4*)(out + ((kb * 16 + l15) * 4 + wq) * 64 + 32 * wh + cb * 16 + 4 * g4) =
+                make_float4(accw[kb][cb][0], accw[kb][cb][1], accw[kb][cb][2], accw[kb][cb][3]);
+}
+
 static int cb_shift(int v) {
     if (v <= 0 || (v & (v - 1))) return -1;
     int s = 0;
@@ -215,7 +379,7 @@ using namespace vae;
 
 extern "C" int vae_convt2x2_bwd_fused_ok(int n_img, int H, int W, int Cin, int Cout) {
     const long npix = (long)n_img * H * W;
-    return g_convt_bwd_mode == 0 && Cin == 64 && Cout == 64 && n_img > 0 && H > 0 && W > 0 && npix % CB_BK == 0 &&
+    return g_convt_bwd_mode != 1 && Cin == 64 && Cout == 64 && n_img > 0 && H > 0 && W > 0 && npix % CB_BK == 0 &&
            npix * 4 * 64 * 2 < (1L << 32);
 }
 
@@ -242,5 +406,34 @@ extern "C" int vae_convt2x2_bwd_fused(const void* dy, const void* x, const void*
     ProfScope prof("convt_bwd_fused_kernel", 2.0 * 2.0 * npix * 256.0 * 64.0, npix * (4.0 * 128 + 128 + 128) + nb * 65536.0, s);
     hipLaunchKernelGGL(convt_bwd_fused_kernel, dim3(nb), dim3(64 * CB_NW), 0, s, p);
     VAE_LAUNCH_CHECK("convt_bwd_fused_kernel");
+    return 0;
+}
+
+extern "C" int vae_head_convt_bwd_fused(const void* y, const float* dl, const float* scale, const float* shift, const float* mean,
+                                        const float* rstd, const float* sums, const float* w_head, int Cout_head, const void* x,
+                                        const void* w_packed, void* dx, float* slab, int n_img, int H, int W, void* stream) {
+    VAE_CHECK(y && dl && scale && shift && mean && rstd && sums && w_head && x && w_packed && dx && slab, "vae_head_convt_bwd_fused: null pointer");
+    VAE_CHECK(Cout_head >= 1 && Cout_head <= 4, "vae_head_convt_bwd_fused: head out_channels=%d not supported (1..4)", Cout_head);
+    const long npix = (long)n_img * H * W;
+    VAE_CHECK(n_img > 0 && H > 0 && W > 0 && npix % CB_BK == 0 && npix * 4 * 64 * 2 < (1L << 32),
+              "vae_head_convt_bwd_fused: n*H*W = %ld must be a positive multiple of %d (and the output below 4 GB)", npix, CB_BK);
+    VAE_CHECK((((uintptr_t)y | (uintptr_t)dl | (uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)dx | (uintptr_t)slab) & 15) == 0,
+              "vae_head_convt_bwd_fused: operands must be 16-byte aligned");
+    HeadConvtBwd p = {};
+    p.y = (const bf16_t*)y; p.dl = dl; p.scale = scale; p.shift = shift; p.mean = mean; p.rstd = rstd; p.sums = sums; p.w = w_head;
+    p.inv_count = (float)(1.0 / (4.0 * (double)npix));
+    p.a = (const bf16_t*)x; p.wd = (const bf16_t*)w_packed; p.dx = (bf16_t*)dx; p.slab = slab;
+    p.npix = (int)npix; p.H = H; p.W = W; p.wshift = cb_shift(W); p.hshift = cb_shift(H); p.ntile = (int)(npix / CB_BK);
+    const int nb = vae_convt2x2_bwd_fused_slabs(n_img, H, W);
+    hipStream_t s = (hipStream_t)stream;
+    // y and dl read once, X read once, dX written once, one slab per workgroup
+    ProfScope prof("head_convt_bwd_kernel", 2.0 * 2.0 * npix * 256.0 * 64.0, npix * (4.0 * 128 + 4.0 * 16 + 128 + 128) + nb * 65536.0, s);
+    switch (Cout_head) {
+        case 1: hipLaunchKernelGGL(head_convt_bwd_kernel<1>, dim3(nb), dim3(64 * CB_NW), 0, s, p); break;
+        case 2: hipLaunchKernelGGL(head_convt_bwd_kernel<2>, dim3(nb), dim3(64 * CB_NW), 0, s, p); break;
+        case 3: hipLaunchKernelGGL(head_convt_bwd_kernel<3>, dim3(nb), dim3(64 * CB_NW), 0, s, p); break;
+        default: hipLaunchKernelGGL(head_convt_bwd_kernel<4>, dim3(nb), dim3(64 * CB_NW), 0, s, p); break;
+    }
+    VAE_LAUNCH_CHECK("head_convt_bwd_kernel");
     return 0;
 }

@@ -15,7 +15,7 @@
 
 #include "model_layout.h"
 
-namespace vae { extern int g_conv1_bwd_mode; extern int g_pool_ymax_mode; int g_fold_defer_mode = 0; int g_slab_reparam_mode = 0; }
+namespace vae { extern int g_conv1_bwd_mode; extern int g_pool_ymax_mode; extern int g_convt_bwd_mode; extern int g_head_sums_mode; int g_fold_defer_mode = 0; int g_slab_reparam_mode = 0; }
 
 namespace {
 using namespace vae_model;
@@ -544,9 +544,18 @@ static int backward_decoder(const Ctx& c, Fork* f, const float* d_recon, const f
     float* slab = nullptr;
     // 1x1 head + bn1
     // [d gamma1 | d beta1] and [d head.weight | d head.bias] are adjacent in the flat layout
-    TRY(vae_head_bwd(d_recon, recon, c.at(w.yd[2]), c.coef(10, 0), c.coef(10, 1), c.coef(10, 2), c.coef(10, 3),
-                     c.P(P_HEAD_W), (float*)c.at(w.headpart), c.G(P_BN1_G), c.G(P_HEAD_W), c.at(w.g[0]), d.N, d.S, d.S,
-                     d.Cout, c.stream));
+    // with the default widths the head's gradient is never stored: its sums (and the logit gradients, 16 bytes per
+    // pixel, parked in gradient buffer 0) now, the tensor itself tile by tile inside the last ConvTranspose's backward
+    const bool head_fused = vae::g_convt_bwd_mode == 0 && vae::g_head_sums_mode == 0 &&
+                            vae_convt2x2_bwd_fused_ok(d.N, s8 << 2, s8 << 2, DEC_CI[2], DEC_CO[2]);
+    if (head_fused)
+        TRY(vae_head_bwd_sums(d_recon, recon, c.at(w.yd[2]), c.coef(10, 0), c.coef(10, 1), c.coef(10, 2), c.coef(10, 3),
+                              c.P(P_HEAD_W), (float*)c.at(w.headpart), c.G(P_BN1_G), c.G(P_HEAD_W), (float*)c.at(w.g[0]), d.N,
+                              d.S, d.S, d.Cout, c.stream));
+    else
+        TRY(vae_head_bwd(d_recon, recon, c.at(w.yd[2]), c.coef(10, 0), c.coef(10, 1), c.coef(10, 2), c.coef(10, 3),
+                         c.P(P_HEAD_W), (float*)c.at(w.headpart), c.G(P_BN1_G), c.G(P_HEAD_W), c.at(w.g[0]), d.N, d.S, d.S,
+                         d.Cout, c.stream));
     // up1, up2, up3 (u = 2, 1, 0): dy in buffer x -> (side: weight grad) ; input grad -> y ; bn backward -> z
     int x = 0;
     hipEvent_t w_prev = nullptr;       // the wgrad that reads the buffer the next dgrad overwrites
@@ -562,7 +571,12 @@ static int backward_decoder(const Ctx& c, Fork* f, const float* d_recon, const f
             const int nsl = vae_convt2x2_bwd_fused_slabs(d.N, hh, hh);
             TRY(slab_take(c, f, (long)nsl * 4 * Co * Ci, &slab));
             TRY(main_after(f, w_prev));    // buffer y was read by the previous iteration's wgrad
-            TRY(vae_convt2x2_bwd_fused(c.at(w.g[x]), xin, c.pk_at(c.pk.ct_d[u]), c.at(w.g[y]), slab, d.N, hh, hh, Ci, Co, c.stream));
+            if (u == 2 && head_fused)
+                TRY(vae_head_convt_bwd_fused(c.at(w.yd[2]), (const float*)c.at(w.g[x]), c.coef(10, 0), c.coef(10, 1), c.coef(10, 2),
+                                             c.coef(10, 3), c.G(P_BN1_G), c.P(P_HEAD_W), d.Cout, xin, c.pk_at(c.pk.ct_d[u]),
+                                             c.at(w.g[y]), slab, d.N, hh, hh, c.stream));
+            else
+                TRY(vae_convt2x2_bwd_fused(c.at(w.g[x]), xin, c.pk_at(c.pk.ct_d[u]), c.at(w.g[y]), slab, d.N, hh, hh, Ci, Co, c.stream));
             TRY(fold_later(f, slab, nsl, 4L * Co * Ci, 0, c.G(P_UP3_W + 4 * u), Co, 4, Ci, 1, 4, 1, 4L * Co, 0));
             w_prev = nullptr;
         } else {

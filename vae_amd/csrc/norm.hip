@@ -149,7 +149,7 @@ int g_head_sums_mode = 0;
 long head_sums_scratch_floats(long npix);
 int head_sums_mfma(const float* drecon, const float* recon, const bf16_t* y, const float* scale, const float* shift,
                    const float* mean, const float* rstd, const float* w, float* scratch, float* sums, float* sums_head,
-                   long npix, int hw, int CO, hipStream_t s);
+                   long npix, int hw, int CO, float* dl_out, hipStream_t s);
 
 static int pow2_shift(int v) {
     if (v <= 0 || (v & (v - 1))) return -1;
@@ -809,7 +809,7 @@ extern "C" int vae_head_bwd(const float* drecon, const float* recon, const void*
 #define GO(CO, PASS, NB) hipLaunchKernelGGL((head_bwd_kernel<CO, PASS>), dim3(NB), dim3(256), 0, s, drecon, recon, yy, scale, shift, mean, rstd, w, sums, inv_count, partial, (bf16_t*)dy, npix, H * W, pow2_shift(H * W))
     if (g_head_sums_mode == 0) {
         // every sum of pass 0 is a contraction over pixels: on the matrix pipe (bn_conv1_bwd.hip)
-        if (int e = head_sums_mfma(drecon, recon, yy, scale, shift, mean, rstd, w, partial, sums, sums_head, npix, H * W, Cout, s))
+        if (int e = head_sums_mfma(drecon, recon, yy, scale, shift, mean, rstd, w, partial, sums, sums_head, npix, H * W, Cout, nullptr, s))
             return e;
     } else {
         switch (Cout) { case 1: GO(1, 0, nb); break; case 2: GO(2, 0, nb); break; case 3: GO(3, 0, nb); break; default: GO(4, 0, nb); }
@@ -825,6 +825,18 @@ extern "C" int vae_head_bwd(const float* drecon, const float* recon, const void*
 #undef GO
     VAE_LAUNCH_CHECK("head_bwd_kernel<1>");
     return 0;
+}
+
+extern "C" int vae_head_bwd_sums(const float* drecon, const float* recon, const void* y, const float* scale,
+                                 const float* shift, const float* mean, const float* rstd, const float* w, float* partial,
+                                 float* sums, float* sums_head, float* dl, int n_img, int H, int W, int Cout, void* stream) {
+    VAE_CHECK(drecon && recon && y && scale && shift && mean && rstd && w && partial && sums && sums_head && dl, "vae_head_bwd_sums: null pointer");
+    VAE_CHECK(n_img > 0 && H > 0 && W > 0 && (long)n_img * H * W < (1L << 31), "vae_head_bwd_sums: bad geometry");
+    VAE_CHECK(Cout >= 1 && Cout <= 4, "vae_head_bwd_sums: out_channels=%d not supported (1..4)", Cout);
+    VAE_CHECK((((uintptr_t)partial | (uintptr_t)dl) & 15) == 0, "vae_head_bwd_sums: partial and dl must be 16-byte aligned");
+    ProfScope prof("head_bwd_sums", 0.0, (double)n_img * H * W * (128.0 + 8.0 * Cout + 16.0), (hipStream_t)stream);
+    return head_sums_mfma(drecon, recon, (const bf16_t*)y, scale, shift, mean, rstd, w, partial, sums, sums_head, (long)n_img * H * W,
+                          H * W, Cout, dl, (hipStream_t)stream);
 }
 
 extern "C" int vae_tanh_bwd_rows(int rows) { return rows < 64 ? rows : 64; }
