@@ -153,7 +153,8 @@ def test_convt_backward_in_one_kernel(L, n, H, W):
         L.call("vae_convt2x2_bwd_fused", L.ptr(dyd), L.ptr(xd), L.ptr(wd), L.ptr(dx), L.ptr(slab), n, H, W, 128, 64, L.current_stream())
 
 
-@pytest.mark.parametrize("n,H,W,Co_head", [(2, 8, 8, 3), (24, 16, 16, 3), (1, 8, 8, 1), (3, 4, 16, 4)])
+# the last case: 640 tiles over 256 workgroups, two or three tiles each (odd and even pass counts, the prefetch ring wrapping)
+@pytest.mark.parametrize("n,H,W,Co_head", [(2, 8, 8, 3), (24, 16, 16, 3), (1, 8, 8, 1), (3, 4, 16, 4), (40, 32, 32, 3)])
 def test_head_and_convt_backward_without_the_gradient_tensor(L, n, H, W, Co_head):
     """bn1 + ReLU + 1x1 head backward followed by the last ConvTranspose's backward (vae/models/vae.py:131-134): the pair
     vae_head_bwd_sums + vae_head_convt_bwd_fused computes the head's gradient tile by tile inside the ConvTranspose kernel

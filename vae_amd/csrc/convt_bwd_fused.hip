@@ -253,31 +253,54 @@ __global__ __launch_bounds__(64 * CB_NW, 1) void head_convt_bwd_kernel(const Hea
 #pragma unroll
         for (int o = 0; o < CO; ++o) swv[o][i] = sc[i] * p.w[o * 64 + c0 + i];
     }
+    // What one lane has in flight for a tile: its 8 channels of the pixel's four output rows, the pixel of X, and ONE of
+    // the four rows' logit gradients (lane cg holds row cg & 3; the eight lanes of a pixel hand them round by
+    // ds_bpermute when the row is formed) -- 24 registers, so that two tiles fit beside the accumulators.
     struct InFlight {
         uint4 y[4];
-        float4 d[4];
+        float4 d;
         uint4 x;
     };
-    InFlight r0;
+    InFlight r0, r1;          // tiles i + 1 and i + 2 while tile i is in the matrix pipe
+    // Buffer loads: a tile past the end is fetched at an out-of-range offset (zeros, no traffic) instead of under a
+    // branch, so every pass of the loop issues the same loads and the counted waits the compiler derives let the
+    // younger set stay in flight (after a conditional fetch it has to assume the loads were not issued).
+    const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, (int)((unsigned)p.npix * 512u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t d_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.dl, 0, (int)((unsigned)p.npix * 64u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, (int)((unsigned)p.npix * 128u), 0x00020000);
+    auto ld16 = [](const __amdgpu_buffer_rsrc_t& rs, unsigned off) {
+        return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
+    };
     auto fetch = [&](InFlight& r, int tile) {
-        const int k = tile * CB_BK + px;          // whole tiles: k < npix
+        const bool ok = tile < p.ntile;
+        const int k = tile * CB_BK + px;          // whole tiles: k < npix when the tile exists
         int h, w, img;
         if (p.wshift >= 0 && p.hshift >= 0) { w = k & (p.W - 1); h = (k >> p.wshift) & (p.H - 1); img = k >> (p.wshift + p.hshift); }
         else { w = k % p.W; const int q = k / p.W; h = q % p.H; img = q / p.H; }
+        const unsigned r00 = (unsigned)(img * 2 * p.H + 2 * h) * (unsigned)(2 * p.W) + (unsigned)(2 * w);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const long rr = ((long)img * 2 * p.H + 2 * h + (j >> 1)) * (2 * p.W) + 2 * w + (j & 1);
-            r.y[j] = *(const uint4*)(p.y + rr * 64 + c0);
-            r.d[j] = *(const float4*)(p.dl + rr * 4);
+            const unsigned rr = r00 + (unsigned)((j >> 1) * 2 * p.W + (j & 1));
+            r.y[j] = ld16(y_rsrc, ok ? rr * 128u + (unsigned)c0 * 2u : 0xFFFFFFFFu);
         }
-        r.x = *(const uint4*)(p.a + (long)k * 64 + c0);
+        {
+            const int j = cg & 3;
+            const unsigned rr = r00 + (unsigned)((j >> 1) * 2 * p.W + (j & 1));
+            r.d = __builtin_bit_cast(float4, ld16(d_rsrc, ok ? rr * 16u : 0xFFFFFFFFu));
+        }
+        r.x = ld16(x_rsrc, ok ? (unsigned)k * 128u + (unsigned)c0 * 2u : 0xFFFFFFFFu);
     };
+    const int lane8 = (lane & ~7) * 4;            // byte index (for ds_bpermute) of the first lane of this pixel
     auto deposit = [&](const InFlight& r, int buf) {
         unsigned char* pbase = smem + buf * CB_STAGE;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const uint32_t yw[4] = {r.y[j].x, r.y[j].y, r.y[j].z, r.y[j].w};
-            const float dl[4] = {r.d[j].x, r.d[j].y, r.d[j].z, r.d[j].w};
+            const float dsrc[4] = {r.d.x, r.d.y, r.d.z, r.d.w};
+            float dl[CO];
+#pragma unroll
+            for (int o = 0; o < CO; ++o)
+                dl[o] = __int_as_float(__builtin_amdgcn_ds_bpermute(lane8 + 4 * j, __float_as_int(dsrc[o])));
             float o8[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -304,10 +327,15 @@ __global__ __launch_bounds__(64 * CB_NW, 1) void head_convt_bwd_kernel(const Hea
     int tile = blockIdx.x;
     fetch(r0, tile);
     deposit(r0, 0);
-    if (tile + G < p.ntile) fetch(r0, tile + G);
-    __syncthreads();                       // the weights and the first tile are in LDS (the prefetch is waited for here too, once)
+    fetch(r0, tile + G);
+    fetch(r1, tile + 2 * G);
+    __syncthreads();                       // the weights and the first tile are in LDS (the prefetches are waited for here too, once)
     int buf = 0;
-    while (true) {
+    // One tile; rs holds the next tile's inputs and is refilled with those of the tile three ahead.  No branch but the
+    // guard of the dX store: a workgroup runs an even number of passes, and a pass past its last tile works on a stage
+    // of zeros for X (nothing is added to dW) and stores nothing -- the loads, the stage writes and the barrier are the
+    // same on every pass, which is what keeps the compiler's counted waits at two tiles of distance.
+    auto one_tile = [&](InFlight& rs) {
         const unsigned char* pb = smem + buf * CB_STAGE;
         const unsigned pbase = (unsigned)(size_t)(cb_lptr_t)smem + (unsigned)(buf * CB_STAGE), qbase = pbase + CB_P;
         f32x4 accd[2];
@@ -325,7 +353,7 @@ __global__ __launch_bounds__(64 * CB_NW, 1) void head_convt_bwd_kernel(const Hea
                 accd[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, gf, accd[nb], 0, 0, 0);
             }
         }
-        {
+        if (tile < p.ntile) {
             bf16_t* dst = p.dx + ((long)tile * CB_BK + rowd) * 64 + 32 * wh + 4 * g4;
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb)
@@ -347,15 +375,16 @@ __global__ __launch_bounds__(64 * CB_NW, 1) void head_convt_bwd_kernel(const Hea
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb) accw[kb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at[cb], gt[kb], accw[kb][cb], 0, 0, 0);
         }
-        const bool more = tile + G < p.ntile;
-        if (more) {
-            deposit(r0, buf ^ 1);
-            if (tile + 2 * G < p.ntile) fetch(r0, tile + 2 * G);
-        }
+        deposit(rs, buf ^ 1);
+        fetch(rs, tile + 3 * G);
         barrier_keep_copies();             // stage buf is read out, stage buf ^ 1 is written
-        if (!more) break;
         tile += G;
         buf ^= 1;
+    };
+    const int mine = (p.ntile - (int)blockIdx.x + G - 1) / G;      // >= 1: the grid is at most ntile wide
+    for (int i = 0; i < mine; i += 2) {
+        one_tile(r0);
+        one_tile(r1);
     }
     float* out = p.slab + (long)blockIdx.x * (4 * 64 * 64);
 #pragma unroll
