@@ -161,8 +161,10 @@ def test_fit_runs_the_reference_epoch_loop(tmp_path):
     m2 = VAEConv(3, 3, 64, 0.1, 32).cuda()
     load_checkpoint(m2, path)                                 # the checkpoint is a plain reference-format state_dict
     assert set(m2.state_dict()) == set(m.state_dict())
-    # the autograd path gives the same kind of record
+    # the autograd path gives the same kind of record.  Its optimizer starts without moment estimates, so the first
+    # steps move every parameter by about lr and the first epoch's loss is back near the untrained one (measured: 802-806
+    # against 804.5); the second epoch is well below it
     hist2 = fit(m, torch.optim.AdamW(m.parameters(), lr=1e-3), Config(kl_weight=1.0, percep_weight=0.0, recon_loss="l1", lr=1e-3,
-                                                                    n_epochs=1, save_model=False),
+                                                                    n_epochs=2, save_model=False),
                 DeviceFeed(imgs, 32, tr), DeviceFeed(imgs, 32, va), fused=False)
-    assert len(hist2) == 1 and hist2[0]["train/loss"] < hist[0]["train/loss"]
+    assert len(hist2) == 2 and hist2[1]["train/loss"] < hist[0]["train/loss"] - 10.0
