@@ -116,7 +116,7 @@ def test_convt2x2_streaming_fwd(L, n, H, W, Ci, Co):
     assert rel_l2(outs[2][0], outs[1][0]) <= 1e-3 and torch.equal(outs[2][1], outs[1][1])
 
 
-@pytest.mark.parametrize("n,H,W", [(2, 8, 8), (16, 16, 16), (3, 4, 16), (1, 8, 8), (40, 16, 16)])
+@pytest.mark.parametrize("n,H,W", [(2, 8, 8), (16, 16, 16), (3, 4, 16), (1, 8, 8), (40, 16, 16), (2, 6, 16), (4, 12, 12)])
 def test_convt_backward_in_one_kernel(L, n, H, W):
     """ConvTranspose2d(64, 64, 2, 2) backward (vae/models/vae.py:131): input gradient and weight gradient from one read of
     dY, against torch autograd on the bf16-rounded operands and against the two separate kernels.  Sizes: one tile, many
@@ -154,7 +154,8 @@ def test_convt_backward_in_one_kernel(L, n, H, W):
 
 
 # the last case: 640 tiles over 256 workgroups, two or three tiles each (odd and even pass counts, the prefetch ring wrapping)
-@pytest.mark.parametrize("n,H,W,Co_head", [(2, 8, 8, 3), (24, 16, 16, 3), (1, 8, 8, 1), (3, 4, 16, 4), (40, 32, 32, 3)])
+@pytest.mark.parametrize("n,H,W,Co_head", [(2, 8, 8, 3), (24, 16, 16, 3), (1, 8, 8, 1), (3, 4, 16, 4), (40, 32, 32, 3),
+                                                   (2, 6, 16, 3), (4, 12, 12, 2)])       # the last two: sizes that are no powers of two
 def test_head_and_convt_backward_without_the_gradient_tensor(L, n, H, W, Co_head):
     """bn1 + ReLU + 1x1 head backward followed by the last ConvTranspose's backward (vae/models/vae.py:131-134): the pair
     vae_head_bwd_sums + vae_head_convt_bwd_fused computes the head's gradient tile by tile inside the ConvTranspose kernel
