@@ -505,6 +505,13 @@ int vae_adamw_clip_step(float* params, const float* grads, float* exp_avg, float
                         float* partial, float grad_mul, float max_norm, double lr, double beta1,
                         double beta2, double eps, double weight_decay, int step, float* grad_norm_out,
                         void* stream);
+/* The same, with vae_elbo_combine (train.py:44-51, the step's loss value) taken along in the first launch when out3 is
+ * not NULL: the loss sums have no reader on the device, so the step saves their launch. */
+int vae_adamw_clip_step_elbo(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n,
+                             float* partial, float grad_mul, float max_norm, double lr, double beta1,
+                             double beta2, double eps, double weight_decay, int step, float* grad_norm_out,
+                             const float* recon_partial, int n_recon, const float* kl_partial, int n_kl,
+                             float kl_weight, float inv_batch, float* out3, void* stream);
 
 #ifdef __cplusplus
 }

@@ -142,6 +142,42 @@ def test_adamw_clip_step_matches_oracle(L, n):
         grads["w"] = grad.clone()      # the oracle clipped in place; the kernel leaves grads untouched
 
 
+def test_adamw_clip_step_takes_the_loss_sums_along(L):
+    """vae_adamw_clip_step_elbo = vae_elbo_combine (train.py:44-51) + vae_adamw_clip_step (train.py:336-338) with the
+    loss sums finished by an extra workgroup of the first launch: the same three loss numbers and the same update, bit
+    for bit."""
+    g = torch.Generator().manual_seed(5)
+    n = 300_001
+    p, grad = torch.randn(n, generator=g), torch.randn(n, generator=g) * 0.01
+    rp, kp = torch.rand(777, generator=g).to(DEV), torch.rand(33, generator=g).to(DEV)
+    outs = []
+    for fused in (False, True):
+        pd, gd = p.to(DEV), grad.to(DEV)
+        md, vd = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        part = torch.empty(L.call("vae_adamw_grid", n), device=DEV)
+        norm, out3 = torch.zeros(1, device=DEV), torch.full((3,), float("nan"), device=DEV)
+        for step in (1, 2):
+            if fused:
+                L.call("vae_adamw_clip_step_elbo", L.ptr(pd), L.ptr(gd), L.ptr(md), L.ptr(vd), n, L.ptr(part), 1.0, 1.0, 1e-3,
+                       0.9, 0.999, 1e-8, 0.01, step, L.ptr(norm), L.ptr(rp), 777, L.ptr(kp), 33, 0.5, 1.0 / 64, L.ptr(out3),
+                       L.current_stream())
+            else:
+                L.call("vae_elbo_combine", L.ptr(rp), 777, L.ptr(kp), 33, 0.5, 1.0 / 64, L.ptr(out3), L.current_stream())
+                L.call("vae_adamw_clip_step", L.ptr(pd), L.ptr(gd), L.ptr(md), L.ptr(vd), n, L.ptr(part), 1.0, 1.0, 1e-3, 0.9,
+                       0.999, 1e-8, 0.01, step, L.ptr(norm), L.current_stream())
+        outs.append((pd.cpu(), md.cpu(), vd.cpu(), norm.cpu(), out3.cpu()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    ref = (rp.double().sum() + 0.5 * kp.double().sum()) / 64
+    assert abs(outs[1][4][0].item() - ref.item()) <= 1e-6 * ref.item()
+    # without out3 the partial-sum pointers are not looked at
+    L.call("vae_adamw_clip_step_elbo", L.ptr(pd), L.ptr(gd), L.ptr(md), L.ptr(vd), n, L.ptr(part), 1.0, 1.0, 1e-3, 0.9, 0.999,
+           1e-8, 0.01, 3, L.ptr(norm), None, 0, None, 0, 0.0, 0.0, None, L.current_stream())
+    with pytest.raises(RuntimeError, match="null partial sums"):
+        L.call("vae_adamw_clip_step_elbo", L.ptr(pd), L.ptr(gd), L.ptr(md), L.ptr(vd), n, L.ptr(part), 1.0, 1.0, 1e-3, 0.9,
+               0.999, 1e-8, 0.01, 4, L.ptr(norm), None, 5, None, 0, 0.0, 0.0, L.ptr(out3), L.current_stream())
+
+
 @pytest.mark.parametrize("L_,C,hw", [(128, 256, 16), (64, 256, 64), (72, 64, 36), (128, 256, 4)])
 def test_multi_pack_transposing_jobs(L, L_, C, hw):
     """the nn.Linear weight jobs of the model's pack (vae/models/vae.py:94 flatten order -> NHWC order, and the

@@ -106,6 +106,8 @@ SIGNATURES = {
     "vae_adamw_grid": (c_int, [c_long]),
     "vae_adamw_clip_step": (None, [P, P, P, P, c_long, P, c_float, c_float, c_double, c_double, c_double,
                                    c_double, c_double, c_int, P, P]),
+    "vae_adamw_clip_step_elbo": (None, [P, P, P, P, c_long, P, c_float, c_float, c_double, c_double, c_double,
+                                        c_double, c_double, c_int, P, P, c_int, P, c_int, c_float, c_float, P, P]),
     "vae_permute_f32": (None, [P, P, P, P, c_long, P]),
     "vae_cast_bf16": (None, [P, P, c_long, P]),
     "vae_model_param_count": (c_long, [P]),

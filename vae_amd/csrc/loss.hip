@@ -5,6 +5,7 @@
 // partials (in double) into  loss = (recon_sum + kl_weight * kl_sum) / batch.
 // HBM-bound: 12 algorithmic bytes per element (two fp32 reads, one fp32 write).
 #include "common.h"
+#include "elbo.h"
 #include "prof.h"
 #include "../../include/vae_hip.h"
 
@@ -111,30 +112,9 @@ __global__ __launch_bounds__(256) void recon_loss_kernel(const float* __restrict
 }
 
 // out[0] = (recon_sum + kl_weight*kl_sum) * inv_batch ; out[1] = recon_sum ; out[2] = kl_sum
-__global__ __launch_bounds__(256) void elbo_combine_kernel(const float* __restrict__ recon_partial,
-                                                           int n_recon,
-                                                           const float* __restrict__ kl_partial,
-                                                           int n_kl, float kl_weight,
-                                                           float inv_batch, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void elbo_combine_kernel(const ElboCombine e) {
     __shared__ double red[4];
-    double a = 0.0, b = 0.0;
-    for (int i = threadIdx.x; i < n_recon; i += blockDim.x) a += (double)recon_partial[i];
-    for (int i = threadIdx.x; i < n_kl; i += blockDim.x) b += (double)kl_partial[i];
-    a = wave_sum_d(a);
-    b = wave_sum_d(b);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (lane == 0) red[w] = a;
-    __syncthreads();
-    double ta = red[0] + red[1] + red[2] + red[3];
-    __syncthreads();
-    if (lane == 0) red[w] = b;
-    __syncthreads();
-    double tb = red[0] + red[1] + red[2] + red[3];
-    if (threadIdx.x == 0) {
-        out[0] = (float)((ta + (double)kl_weight * tb) * (double)inv_batch);
-        out[1] = (float)ta;
-        out[2] = (float)tb;
-    }
+    elbo_combine_body(e, red);
 }
 
 }  // namespace vae
@@ -240,8 +220,8 @@ extern "C" int vae_elbo_combine(const float* recon_partial, int n_recon, const f
                                 void* stream) {
     VAE_CHECK(out3 && (recon_partial || n_recon == 0) && (kl_partial || n_kl == 0),
               "vae_elbo_combine: null pointer");
-    hipLaunchKernelGGL(elbo_combine_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream,
-                       recon_partial, n_recon, kl_partial, n_kl, kl_weight, inv_batch, out3);
+    const ElboCombine e = {recon_partial, kl_partial, out3, n_recon, n_kl, kl_weight, inv_batch};
+    hipLaunchKernelGGL(elbo_combine_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, e);
     VAE_LAUNCH_CHECK("elbo_combine_kernel");
     return 0;
 }

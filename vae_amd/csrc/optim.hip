@@ -6,17 +6,26 @@
 // into the clip coefficient and applies the decoupled-weight-decay Adam update to its slice.
 // HBM-bound: 28 algorithmic bytes per parameter (g, p, m, v read; p, m, v written).
 #include "common.h"
+#include "elbo.h"
 #include "prof.h"
 #include "../../include/vae_hip.h"
 
 namespace vae {
 
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ partial) {
+// With e.out set the launch has one workgroup more, which finishes the step's loss sums instead (they have no reader on
+// the device: taking them along here saves the step a launch of its own).
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ partial, int nsum,
+                                                    const ElboCombine e) {
+    if ((int)blockIdx.x >= nsum) {
+        __shared__ double redd[4];
+        elbo_combine_body(e, redd);
+        return;
+    }
     __shared__ float red[8];
     float acc = 0.f;
     const long n4 = n >> 2;
     const float4* g4 = (const float4*)g;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)nsum * blockDim.x) {
         const float4 v = g4[i];
         acc += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
     }
@@ -90,7 +99,18 @@ extern "C" int vae_adamw_grid(long n) {
 extern "C" int vae_adamw_clip_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n,
                                    float* partial, float grad_mul, float max_norm, double lr, double beta1, double beta2,
                                    double eps, double weight_decay, int step, float* grad_norm_out, void* stream) {
+    return vae_adamw_clip_step_elbo(params, grads, exp_avg, exp_avg_sq, n, partial, grad_mul, max_norm, lr, beta1, beta2, eps,
+                                    weight_decay, step, grad_norm_out, nullptr, 0, nullptr, 0, 0.f, 0.f, nullptr, stream);
+}
+
+extern "C" int vae_adamw_clip_step_elbo(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n,
+                                        float* partial, float grad_mul, float max_norm, double lr, double beta1, double beta2,
+                                        double eps, double weight_decay, int step, float* grad_norm_out,
+                                        const float* recon_partial, int n_recon, const float* kl_partial, int n_kl,
+                                        float kl_weight, float inv_batch, float* out3, void* stream) {
     VAE_CHECK(params && grads && exp_avg && exp_avg_sq && partial, "vae_adamw_clip_step: null pointer");
+    VAE_CHECK(!out3 || ((recon_partial || n_recon == 0) && (kl_partial || n_kl == 0) && n_recon >= 0 && n_kl >= 0),
+              "vae_adamw_clip_step_elbo: null partial sums");
     VAE_CHECK(n > 0 && step >= 1, "vae_adamw_clip_step: n=%ld, step=%d must be positive", n, step);
     VAE_CHECK((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0,
               "vae_adamw_clip_step: buffers must be 16-byte aligned");
@@ -101,7 +121,8 @@ extern "C" int vae_adamw_clip_step(float* params, const float* grads, float* exp
     const float bc2s = (float)sqrt(1.0 - pow(beta2, (double)step));
     {
         ProfScope prof("sumsq_kernel", 0.0, 4.0 * n, s);
-        hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, s, grads, n, partial);
+        const ElboCombine e = {recon_partial, kl_partial, out3, n_recon, n_kl, kl_weight, inv_batch};
+        hipLaunchKernelGGL(sumsq_kernel, dim3(grid + (out3 ? 1 : 0)), dim3(256), 0, s, grads, n, partial, grid, e);
     }
     VAE_LAUNCH_CHECK("sumsq_kernel");
     {

@@ -28,15 +28,19 @@ class FlatAdamW:
         for p in self.model.parameters():
             p.grad = None
 
-    def step_flat(self, model=None, max_norm=1.0):
-        """clip_grad_norm_(max_norm) + AdamW step on model.flat_grads, then refresh the bf16 weights."""
+    def step_flat(self, model=None, max_norm=1.0, elbo=None):
+        """clip_grad_norm_(max_norm) + AdamW step on model.flat_grads, then refresh the bf16 weights.
+        elbo: the arguments of vae_elbo_combine (recon partials, count, KL partials, count, kl_weight, 1/batch, out3);
+        the step's loss sums are then finished inside the first launch here instead of in a launch of their own."""
         m = self.model
         _lib.check_device(m.flat_params)
         self.step_count += 1
-        _lib.call("vae_adamw_clip_step", m.flat_params.data_ptr(), m.flat_grads.data_ptr(), self.exp_avg.data_ptr(),
+        e = elbo if elbo is not None else (None, 0, None, 0, 0.0, 0.0, None)
+        _lib.call("vae_adamw_clip_step_elbo", m.flat_params.data_ptr(), m.flat_grads.data_ptr(), self.exp_avg.data_ptr(),
                   self.exp_avg_sq.data_ptr(), m.flat_params.numel(), self._partial.data_ptr(), float(self.grad_mul),
                   float(max_norm if max_norm is not None else 0.0), self.lr, self.betas[0], self.betas[1], self.eps,
-                  self.weight_decay, self.step_count, self.grad_norm.data_ptr(), _lib.current_stream())
+                  self.weight_decay, self.step_count, self.grad_norm.data_ptr(), e[0], int(e[1]), e[2], int(e[3]),
+                  float(e[4]), float(e[5]), e[6], _lib.current_stream())
         m.repack_weights()
 
     def step(self):

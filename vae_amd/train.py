@@ -206,7 +206,11 @@ class FusedStep:
         _lib.call("vae_recon_loss_fwd_bwd", recon.data_ptr(), inputs.data_ptr(), d_recon.data_ptr(), partial.data_ptr(),
                   recon.numel(), self.kind, 1.0 / batch, s)
         klp, nkl = m.kl_partials(state)
-        _lib.call("vae_elbo_combine", partial.data_ptr(), grid, klp, nkl, self.kl_weight, 1.0 / batch, out3.data_ptr(), s)
+        elbo = (partial.data_ptr(), grid, klp, nkl, self.kl_weight, 1.0 / batch, out3.data_ptr())
+        # the loss value has no reader on the device: FlatAdamW finishes its sums inside its own first launch
+        defer = hasattr(self.optimizer, "step_flat")
+        if not defer:
+            _lib.call("vae_elbo_combine", *elbo, s)
         kl_scale = self.kl_weight / batch
         if self.reducer is None:
             m.backward_raw(state, d_recon, None, None, kl_scale, -1)
@@ -219,7 +223,7 @@ class FusedStep:
         if self._grad_views is None or self._grad_views[0].data_ptr() != m.flat_grads.data_ptr():
             self._grad_views = m.grad_views()
         if hasattr(self.optimizer, "step_flat"):
-            self.optimizer.step_flat(m, self.max_norm)
+            self.optimizer.step_flat(m, self.max_norm, elbo)
         else:
             for p, g in zip(m._ordered_params(), self._grad_views):
                 p.grad = g
