@@ -20,7 +20,10 @@
 extern "C" {
 #endif
 
-#define VAE_HIP_VERSION 1
+/* ABI revision: bumped whenever a struct layout, an argument list or the meaning of a returned size changes.
+ * A binding compares vae_version() with the value it was written for before it makes any other call (vae_amd/_lib.py
+ * does); vae_model_cfg carries its own size as a second check that needs no call order. */
+#define VAE_HIP_VERSION 3
 
 /* reconstruction-term kinds */
 #define VAE_RECON_L1 0          /* F.l1_loss(reduction="sum")                 vae/training/train.py:55        */
@@ -67,8 +70,10 @@ int vae_prof_stop(char* names, int* launches, double* total_ms, double* flops, d
  * vae_model_backward(stage = -1) folds every split-K slab in one launch at its end (default), 1 in one launch per stage;
  * "slab_reparam" = 0 the whole-model passes let the reparameterisation kernels add up the split-K slabs of the latent GEMMs
  * (default), 1 a finishing kernel does; "convt_bwd" = 0 the 64 -> 64 ConvTranspose backward as one kernel that also makes the head's gradient
- * on the way (default), 1 as separate input- and weight-gradient kernels, 2 one kernel reading the stored gradient.  Not thread-safe: set it while nothing is being
- * launched. */
+ * on the way (default), 1 as separate input- and weight-gradient kernels, 2 one kernel reading the stored gradient.  Unknown keys and
+ * values outside a key's range are rejected.  Not thread-safe: set it while nothing is being launched, and never
+ * between a vae_model_forward and its vae_model_backward: some keys change the workspace carving that
+ * vae_model_workspace_bytes and both passes derive from the config. */
 int vae_set_tuning(const char* key, int value);
 /* Diagnostic aid: device buffer (>= 128 bytes per workgroup of the launch under study) that the diagnostic kernel
  * variants selected with vae_set_tuning write cycle-counter stamps to; NULL (default) = none. */
@@ -94,7 +99,9 @@ int vae_elbo_combine(const float* recon_partial, int n_recon, const float* kl_pa
  *   vae_elbo_combine gives for the partials of vae_recon_loss_fwd_bwd), out3[2] = 0;  grad as above (may be NULL).
  * n_elems above vae_recon_loss_static_max_elems() (2^25 = 33 554 432: one partial sum per 2048 elements) is rejected.  It calls no hipMalloc / hipFree; work is
  * enqueued on `stream` only.  Every call on one GPU shares that GPU's array: calls that overlap on one GPU
- * (different streams, or host threads) race -- serialise them or use vae_recon_loss_fwd_bwd. */
+ * (different streams, or host threads) race -- serialise them or use vae_recon_loss_fwd_bwd.  The first call on a
+ * device resolves that device's copy of the array (hipGetSymbolAddress, which may load the code object): make it
+ * outside any graph capture; every later call on that device only enqueues two kernels. */
 long vae_recon_loss_static_max_elems(void);
 int vae_recon_loss_fwd_bwd_static(const float* recon, const float* target, float* grad, float* out3,
                                   long n_elems, int kind, float grad_scale, void* stream);
@@ -437,6 +444,9 @@ int vae_cast_bf16(const float* src, void* dst_bf16, long n, void* stream);
  * workspace      : vae_model_workspace_bytes(cfg) bytes; holds the activations between forward
  *                  and backward, so one workspace per in-flight batch. */
 typedef struct vae_model_cfg {
+    unsigned struct_size;    /* = sizeof(vae_model_cfg) of the header the caller was built against; every vae_model_*
+                              * entry point rejects a config whose size differs from the library's (a caller built
+                              * against another revision of this struct would otherwise hand over garbage fields) */
     int batch, in_channels, out_channels, latent, image_size;
     int train;               /* 1: model.train() -- batch statistics, dropout, running stats move */
     double p_dropout;

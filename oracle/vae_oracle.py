@@ -473,14 +473,10 @@ def _log_f32(u: np.ndarray) -> np.ndarray:
 
 
 def _sqrt_f32(x: np.ndarray) -> np.ndarray:
-    """sqrt by three Newton steps from an integer first guess, fp32 ops only
-    (each of /, +, * individually rounded; x <= 0 -> 0)."""
+    """correctly rounded fp32 square root (IEEE: numpy's sqrt on float32 is; the kernel's sqrtf is too); x <= 0 -> 0."""
     pos = x > _F(0.0)
     xs = np.where(pos, x, _F(1.0)).astype(np.float32)
-    y = (np.uint32(0x1FBD1DF5) + (xs.view(np.uint32) >> np.uint32(1))).astype(np.uint32).view(np.float32)
-    for _ in range(3):
-        y = (_F(0.5) * (y + (xs / y).astype(np.float32)).astype(np.float32)).astype(np.float32)
-    return np.where(pos, y, _F(0.0)).astype(np.float32)
+    return np.where(pos, np.sqrt(xs, dtype=np.float32), _F(0.0)).astype(np.float32)
 
 
 def _sincos_quarter(r: np.ndarray):

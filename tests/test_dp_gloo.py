@@ -101,6 +101,43 @@ def _worker(rank, port, outdir):
         m._bn_stats = torch.arange(6, dtype=torch.float32) * (rank + 1)      # running statistics drift apart per rank
         dp.sync_bn_stats(m)
         assert torch.equal(m._bn_stats, torch.arange(6, dtype=torch.float32) * 1.5)
+        # ---- 4. fit() on two ranks: the running statistics are averaged BEFORE the validation pass, so every rank
+        # validates the same model and the checkpoint rank 0 writes is the model whose loss was compared.  The GPU
+        # steps are replaced by stand-ins (this process has no GPU); the epoch loop itself is the code under test.
+        import vae_amd.data as vdata
+        import vae_amd.train as vtrain
+        seen = {"val_stats": [], "saved": []}
+
+        class Toy(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.w = torch.nn.Parameter(torch.zeros(1))
+                self._bn_stats = torch.zeros(4)
+
+        toy = Toy()
+
+        def fake_train_step(model, optimizer, x, config):
+            model._bn_stats += float(rank + 1)               # per-rank batch statistics: the running stats drift apart
+            return torch.tensor(1.0)
+
+        def fake_val_step(model, x, config):
+            seen["val_stats"].append(model._bn_stats.clone())
+            return model._bn_stats.sum() * 0 + 2.0 - 0.1 * len(seen["val_stats"])      # improves every epoch
+
+        def fake_save(model, path):
+            seen["saved"].append(model._bn_stats.clone())
+
+        old = vtrain.train_step, vtrain.val_step, vdata.save_checkpoint
+        vtrain.train_step, vtrain.val_step, vdata.save_checkpoint = fake_train_step, fake_val_step, fake_save
+        try:
+            conf = vtrain.Config(n_epochs=2, save_model=True, percep_weight=0.0, kl_weight=1.0)
+            hist = vtrain.fit(toy, None, conf, [torch.zeros(1)] * 3, [torch.zeros(1)], fused=False)
+        finally:
+            vtrain.train_step, vtrain.val_step, vdata.save_checkpoint = old
+        # epoch 1: ranks added 3*1 and 3*2 -> mean 4.5; epoch 2: 4.5 + 3*(rank+1) -> mean 9.0
+        assert [float(t[0]) for t in seen["val_stats"]] == [4.5, 9.0], seen["val_stats"]
+        assert len(hist) == 2 and hist[1]["val/loss"] < hist[0]["val/loss"]
+        assert ([float(t[0]) for t in seen["saved"]] == [4.5, 9.0]) if rank == 0 else (seen["saved"] == [])
         torch.save({"flat": flat, "loss": loss.detach()}, os.path.join(outdir, f"r{rank}.pt"))
     finally:
         dist.destroy_process_group()

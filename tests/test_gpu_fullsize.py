@@ -24,8 +24,10 @@ def _model(latent, size, seed=1337):
     return m
 
 
-def test_cfg2_forward_and_loss_against_the_oracle():
-    N, L, S, p = 512, 128, 32, 0.1
+@pytest.mark.parametrize("L,kind,klw", [(128, "l1", 1.0), (512, "mse", 4.0)], ids=["cfg2", "cfg5"])
+def test_cfg2_cfg5_forward_and_loss_against_the_oracle(L, kind, klw):
+    """benchmark configs 2 (latent 128, L1 + KL) and 5 (latent 512, beta = 4, MSE + KL) at their full batch of 512"""
+    N, S, p = 512, 32, 0.1
     m = _model(L, S).train()
     m.rng_step = 5
     sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
@@ -36,13 +38,13 @@ def test_cfg2_forward_and_loss_against_the_oracle():
     for b, (C, H) in enumerate([(64, S), (128, S // 2), (256, S // 4), (256, S // 8)]):
         k = O.philox_keep_mask(N * H * H * C, p, 1337, b, 5, 0)
         masks.append(torch.from_numpy(k).view(N, H, H, C).permute(0, 3, 1, 2))
-    loss_ref, r_ref, mu_ref, lv_ref, g_ref, _ = O.loss_and_grads(x, sd, eps, "l1", 1.0, True, p, masks)
+    loss_ref, r_ref, mu_ref, lv_ref, g_ref, _ = O.loss_and_grads(x, sd, eps, kind, klw, True, p, masks)
     # the contract's bf16 figure on the outputs; mu / logvar sit behind eight bf16 conv + BatchNorm blocks
     assert rel_l2(recon.detach().cpu(), r_ref) <= 2e-2
     assert rel_l2(mu.detach().cpu(), mu_ref) <= 5e-2
     assert rel_l2(logvar.detach().cpu(), lv_ref) <= 5e-2
-    from vae_amd.train import Config, l1_kl_percep_loss
-    loss = l1_kl_percep_loss(recon, x.to(DEV), mu, logvar, Config(kl_weight=1.0, percep_weight=0.0), None)
+    from vae_amd.train import Config, vae_loss
+    loss = vae_loss(recon, x.to(DEV), mu, logvar, kind, None, Config(kl_weight=klw, percep_weight=0.0))
     assert abs(float(loss.detach()) - float(loss_ref)) <= 1e-2 * abs(float(loss_ref))
     # gradients: bf16 rounding flips a few ReLU / max-pool routes per thousand, which no bf16 pipeline reproduces element
     # by element; over a batch of 512 the flips average out and direction and size of every tensor's gradient must agree
@@ -64,7 +66,7 @@ def test_cfg2_forward_and_loss_against_the_oracle():
         # conv1.net.4.bias from 1.09 to 1.106.
         assert cos >= 0.90 and 0.85 <= ratio <= 1.15, (name, cos, ratio)
     total = dot / (n_got * n_ref) ** 0.5
-    print("gradient cosine at batch 512: all parameters", total, "worst tensor", worst)
+    print(f"latent {L}: gradient cosine at batch 512: all parameters", total, "worst tensor", worst)
     assert total >= 0.995
 
 
@@ -97,7 +99,37 @@ def test_cfg4_full_size_forward_and_loss_against_the_oracle_fixture():
     assert np.abs(per_image - z["per_image_l1"]).max() <= 2e-2 * np.abs(z["per_image_l1"]).max()
 
 
-@pytest.mark.parametrize("N,L,S", [(512, 128, 32), (1024, 256, 64)])
+@pytest.mark.parametrize("mode,tol", [("bf16", 2e-2), ("fp32", 1e-5)])
+def test_cfg5_decode_eval_mode_against_the_oracle(mode, tol):
+    """Benchmark config 5's sampling leg at its full size: recon = decode(z) in eval mode (vae/models/vae.py:114-122;
+    running statistics, no dropout, no RNG), latent 512, batch 4096, 32x32, against the fp32 oracle's decoder -- 2e-2 on
+    the bf16 path, 1e-5 in the fp32 mode.  Affine BatchNorm parameters and running statistics are moved off their
+    initial (1, 0, 0, 1) so that they matter."""
+    from vae_amd.vae import VAEConv
+    N, L, S = 4096, 512, 32
+    torch.manual_seed(1337)
+    m = VAEConv(3, 3, L, 0.1, S)
+    sd = O.perturb_norm_params({k: v.detach().clone() for k, v in m.state_dict().items()}, 5)
+    m.load_state_dict(sd)
+    m.to(DEV).eval().set_precision(mode)
+    z = torch.randn(N, L, generator=torch.Generator().manual_seed(11))
+    with torch.no_grad():
+        ref = O.decode(z, sd, train=False)
+        got = m.decode(z.to(DEV)).cpu()
+    assert got.shape == (N, 3, S, S) and torch.isfinite(got).all()
+    err = rel_l2(got, ref)
+    worst = float((got - ref).abs().max())
+    print(f"cfg5 decode, batch {N}, {mode}: relative L2 {err:.2e}, largest absolute difference {worst:.2e}")
+    assert err <= tol, (mode, err)
+    assert worst <= (3e-2 if mode == "bf16" else 2e-6)
+    # nothing moved: eval mode leaves the running statistics and the counters alone
+    after = m.state_dict()
+    for k in sd:
+        if "running" in k or "num_batches" in k:
+            assert torch.equal(after[k].cpu(), sd[k]), k
+
+
+@pytest.mark.parametrize("N,L,S", [(512, 128, 32), (1024, 256, 64), (512, 512, 32)])
 def test_full_size_properties(N, L, S):
     from vae_amd.optim import FlatAdamW
     from vae_amd.train import Config, FusedStep

@@ -28,16 +28,25 @@ def reference(recon, target, kind, scale):
 def test_static_entry_point_equals_the_allocating_one(kind):
     L.load()
     g = torch.Generator(device=DEV).manual_seed(7 + kind)
-    # first call: 512 x 3 x 32 x 32 (the full 2048-workgroup grid); second: a ragged, much smaller input (few workgroups)
+    # first call: 512 x 3 x 32 x 32 (768 workgroups = 768 partial sums in the fixed array); second: a ragged, much
+    # smaller input (8 workgroups), which must not see the first call's leftovers
     for n in (512 * 3 * 32 * 32, 5 * 3 * 32 * 32 + 3):
         recon = torch.rand(n, device=DEV, generator=g) * 0.98 + 0.01
         target = torch.rand(n, device=DEV, generator=g)
         want_grad, want3 = reference(recon, target, kind, 0.125)
         grad = torch.full_like(recon, float("nan"))
         out3 = torch.full((3,), float("nan"), device=DEV)
+        # prime call: the first call on a device resolves the address of the array (and may load the code object)
+        L.call("vae_recon_loss_fwd_bwd_static", recon.data_ptr(), target.data_ptr(), None, out3.data_ptr(), n, kind,
+               0.125, L.current_stream())
+        torch.cuda.synchronize()
+        free0, _ = torch.cuda.mem_get_info()
+        held0 = torch.cuda.memory_allocated()
         L.call("vae_recon_loss_fwd_bwd_static", recon.data_ptr(), target.data_ptr(), grad.data_ptr(), out3.data_ptr(), n, kind,
                0.125, L.current_stream())
         torch.cuda.synchronize()
+        # no device memory was taken by the call: neither from the driver (hipMemGetInfo) nor from torch's allocator
+        assert torch.cuda.mem_get_info()[0] == free0 and torch.cuda.memory_allocated() == held0
         assert torch.equal(grad, want_grad), (kind, n)
         assert torch.equal(out3, want3), (kind, n, out3.tolist(), want3.tolist())
         # forward only (grad = NULL): same sum

@@ -126,12 +126,17 @@ SIGNATURES = {
 
 class ModelCfg(ctypes.Structure):
     """mirror of struct vae_model_cfg (include/vae_hip.h)."""
-    _fields_ = [("batch", c_int), ("in_channels", c_int), ("out_channels", c_int), ("latent", c_int),
+    _fields_ = [("struct_size", c_uint), ("batch", c_int), ("in_channels", c_int), ("out_channels", c_int), ("latent", c_int),
                 ("image_size", c_int), ("train", c_int), ("p_dropout", c_double),
                 ("seed", c_ulonglong), ("step", c_uint), ("rank", c_uint), ("side_stream", c_void_p),
                 ("precision", c_int), ("batches_tracked", c_void_p)]
 
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        self.struct_size = ctypes.sizeof(ModelCfg)      # the library compares it with its own sizeof(vae_model_cfg)
 
+
+ABI_VERSION = 3                          # VAE_HIP_VERSION of the include/vae_hip.h these signatures were written for
 PRECISIONS = {"bf16": 0, "fp32": 1}      # VAE_PRECISION_* of include/vae_hip.h
 
 
@@ -156,6 +161,10 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = c_int if res is None else res
         fn.argtypes = args
+    built = lib.vae_version()
+    if built != ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH} reports ABI revision {built}, this binding was written for {ABI_VERSION}: "
+                           "rebuild the library (make -C vae_amd/csrc) from the same tree as vae_amd/_lib.py")
     _lib = lib
     return lib
 

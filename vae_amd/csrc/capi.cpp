@@ -77,50 +77,35 @@ extern "C" int vae_set_debug_buffer(void* dev_ptr) {
     return 0;
 }
 // Measurement aid: selects between kernel variants that compute the same result, for A/B timing in one process.
+// Every key has a closed range; a value outside it is rejected instead of being stored.
 extern "C" int vae_set_tuning(const char* key, int value) {
-    if (key && !strcmp(key, "conv3_wide")) {          // 0 auto, 1 always the 4-wave kernel, 2 the 8-wave kernel wherever legal
-        vae::g_conv3_wide_mode = value;
-        return 0;
-    }
-    if (key && !strcmp(key, "conv3_ksplit")) {        // 0 auto, 1 never split K inside the workgroup, 2 wherever legal
-        vae::g_conv3_ksplit_mode = value;
-        return 0;
-    }
-    if (key && !strcmp(key, "wgrad_pc")) {            // conv3x3 weight gradient, copying and computing waves separated: 0 by K range, 1 always, 2 never
-        vae::g_wgrad_pc_mode = value;
-        return 0;
-    }
-    if (key && !strcmp(key, "conv3_ws64")) {          // weight-stationary conv3x3 for 64 input channels: 0 where its jobs fill the chip, 1 never, 2 wherever legal
-        vae::g_conv3_ws64_mode = value;
-        return 0;
-    }
-    if (key && !strcmp(key, "conv1_bwd")) {           // first conv's BatchNorm backward + weight gradient: 0 the one-pass kernel where Cin <= 3, 1 separate passes
-        vae::g_conv1_bwd_mode = value;
-        return 0;
-    }
-    if (key && !strcmp(key, "pool_ymax")) {           // pooled BatchNorm backward sums from the stored window maxima: 0 yes, 1 re-read the windows
-        vae::g_pool_ymax_mode = value;
-        return 0;
-    }
-    if (key && !strcmp(key, "head_sums")) {           // the 1x1 head's backward sums: 0 on the matrix pipe, 1 in vector registers
-        vae::g_head_sums_mode = value;
-        return 0;
-    }
-    if (key && !strcmp(key, "fold_defer")) {          // whole-pass backward: 0 one slab-fold launch at the end, 1 one per stage
-        vae::g_fold_defer_mode = value;
-        return 0;
-    }
-    if (key && !strcmp(key, "slab_reparam")) {        // split-K slabs of the latent GEMMs: 0 added up by the reparameterisation kernels, 1 by a finishing kernel
-        vae::g_slab_reparam_mode = value;
-        return 0;
-    }
-    if (key && !strcmp(key, "convt_bwd")) {           // 64 -> 64 ConvTranspose backward: 0 one kernel (dY read once), 1 separate input- and weight-gradient kernels
-        vae::g_convt_bwd_mode = value;
-        return 0;
-    }
-    if (key && !strcmp(key, "stream_gemm")) {         // 0 the streaming GEMM where it pays, 1 never (tiled GEMM), 2 wherever legal
-        vae::g_stream_gemm_mode = value;
-        return 0;
+    struct Key {
+        const char* name;
+        int* slot;
+        int lo, hi;
+    };
+    static const Key keys[] = {
+        {"conv3_wide", &vae::g_conv3_wide_mode, 0, 2},        // 0 auto, 1 always the 4-wave kernel, 2 the 8-wave kernel wherever legal
+        {"conv3_ksplit", &vae::g_conv3_ksplit_mode, 0, 2},    // 0 auto, 1 never split K inside the workgroup, 2 wherever legal
+        {"wgrad_pc", &vae::g_wgrad_pc_mode, 0, 2},            // conv3x3 weight gradient, copying and computing waves separated: 0 by K range, 1 always, 2 never
+        {"conv3_ws64", &vae::g_conv3_ws64_mode, 0, 3},        // weight-stationary conv3x3 for 64 input channels: 0 where its jobs fill the chip, 1 never, 2 wherever legal, 3 as 0, hand-pipelined
+        {"conv1_bwd", &vae::g_conv1_bwd_mode, 0, 1},          // first conv's BatchNorm backward + weight gradient: 0 the one-pass kernel where Cin <= 3, 1 separate passes
+        {"pool_ymax", &vae::g_pool_ymax_mode, 0, 1},          // pooled BatchNorm backward sums from the stored window maxima: 0 yes, 1 re-read the windows
+        {"head_sums", &vae::g_head_sums_mode, 0, 1},          // the 1x1 head's backward sums: 0 on the matrix pipe, 1 in vector registers
+        {"fold_defer", &vae::g_fold_defer_mode, 0, 1},        // whole-pass backward: 0 one slab-fold launch at the end, 1 one per stage
+        {"slab_reparam", &vae::g_slab_reparam_mode, 0, 1},    // split-K slabs of the latent GEMMs: 0 added up by the reparameterisation kernels, 1 by a finishing kernel
+        {"convt_bwd", &vae::g_convt_bwd_mode, 0, 2},          // 64 -> 64 ConvTranspose backward: 0 one kernel that also makes the head's gradient, 1 separate kernels, 2 one kernel reading the stored gradient
+        {"stream_gemm", &vae::g_stream_gemm_mode, 0, 2},      // 0 the streaming GEMM where it pays, 1 never (tiled GEMM), 2 wherever legal
+    };
+    for (const Key& k : keys) {
+        if (key && !strcmp(key, k.name)) {
+            if (value < k.lo || value > k.hi) {
+                vae::set_error("vae_set_tuning: %s=%d out of range [%d, %d]", k.name, value, k.lo, k.hi);
+                return 2;
+            }
+            *k.slot = value;
+            return 0;
+        }
     }
     vae::set_error("vae_set_tuning: unknown key '%s'", key ? key : "(null)");
     return 1;

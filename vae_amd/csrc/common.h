@@ -115,7 +115,7 @@ __device__ __forceinline__ void philox_block(const PhiloxKey& k, uint32_t blk, u
     philox4x32_10(out, k.seed_lo, k.seed_hi);
 }
 
-// fp32 Box-Muller made only of individually rounded mul/add/div/sqrt (no fma, no
+// fp32 Box-Muller made only of individually (correctly) rounded mul/add/div/sqrt (no fma, no
 // libm), so that host restatements reproduce it bit for bit.
 __device__ __forceinline__ float log_f32_exact(float u) {
     const uint32_t bits = __float_as_uint(u);
@@ -134,15 +134,12 @@ __device__ __forceinline__ float log_f32_exact(float u) {
     return __fadd_rn(__fmul_rn((float)e, 0.69314718055994530942f), __fmul_rn(p, s));
 }
 
-// sqrt by three Newton steps from an integer-arithmetic first guess: every step is one
-// correctly rounded divide, add and multiply (the hardware v_sqrt_f32 is not correctly
-// rounded, so it cannot be reproduced on the host).
+// Correctly rounded fp32 square root: sqrtf() compiles to v_sqrt_f32 plus the compiler's fix-up sequence (hipcc's
+// default -fhip-fp32-correctly-rounded-divide-sqrt), i.e. the IEEE result, which is what numpy.sqrt returns on the
+// host -- so the stream stays reproducible bit for bit.  (__fsqrt_rn is NOT this: it maps to the native, 1-ulp
+// instruction.)  A third of the cost of the three-divide Newton iteration it replaces.
 __device__ __forceinline__ float sqrt_f32_exact(float x) {
-    if (!(x > 0.f)) return 0.f;
-    float y = __uint_as_float(0x1FBD1DF5u + (__float_as_uint(x) >> 1));
-#pragma unroll
-    for (int i = 0; i < 3; ++i) y = __fmul_rn(0.5f, __fadd_rn(y, __fdiv_rn(x, y)));
-    return y;
+    return x > 0.f ? __builtin_sqrtf(x) : 0.f;
 }
 
 __device__ __forceinline__ void sincos_quarter(float r, float& sn, float& cs) {

@@ -22,24 +22,29 @@ __device__ __forceinline__ void loss_elem(float r, float t, float gs, float& l, 
         l = d * d;
         g = 2.f * d * gs;
     } else if (KIND == VAE_RECON_BCE) {
-        // F.binary_cross_entropy clamps each log at >= -100
-        const float lr = fmaxf(logf(r), -100.f);
-        const float l1r = fmaxf(log1pf(-r), -100.f);
+        // F.binary_cross_entropy: -(t max(log r, -100) + (1 - t) max(log(1 - r), -100)) with 1 - r rounded to fp32 first,
+        // as ATen forms it.  Logs on the hardware log2 (v_log_f32, 1 ulp) times ln 2: ~1e-7 per term, against the
+        // 1e-5 bar on the sum; the accurate logf + log1pf pair made this kernel ALU-bound at a third of the HBM rate.
+        const float lr = fmaxf(__logf(r), -100.f);
+        const float l1r = fmaxf(__logf(1.f - r), -100.f);
         l = -(t * lr + (1.f - t) * l1r);
-        // d/dr = (r - t) / max(r (1 - r), 1e-12)   (ATen binary_cross_entropy_backward)
-        g = (r - t) / fmaxf(r * (1.f - r), 1e-12f) * gs;
+        // d/dr = (r - t) / max(r (1 - r), 1e-12)   (ATen binary_cross_entropy_backward); v_rcp_f32 is 1 ulp
+        g = (r - t) * __builtin_amdgcn_rcpf(fmaxf(r * (1.f - r), 1e-12f)) * gs;
     } else if (KIND == VAE_RECON_BCE_LOGITS) {
         // binary_cross_entropy_with_logits on logits clamped to [-10, 10]
         const float x = fminf(fmaxf(r, -10.f), 10.f);
         const float e = __expf(-fabsf(x));
-        l = fmaxf(x, 0.f) - x * t + log1pf(e);
-        const float sg = x >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+        const float inv = __builtin_amdgcn_rcpf(1.f + e);
+        l = fmaxf(x, 0.f) - x * t + __logf(1.f + e);          // e in [e^-10, 1]: 1 + e carries e to 2^-24 absolute
+        const float sg = x >= 0.f ? inv : e * inv;
         g = (r >= -10.f && r <= 10.f) ? (sg - t) * gs : 0.f;   // clamp passes no gradient outside
     } else {
-        // F.binary_cross_entropy_with_logits itself: max(x,0) - x t + log1p(exp(-|x|)), gradient sigmoid(x) - t
-        const float e = expf(-fabsf(r));
-        l = fmaxf(r, 0.f) - r * t + log1pf(e);
-        const float sg = r >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+        // F.binary_cross_entropy_with_logits itself: max(x,0) - x t + log1p(exp(-|x|)), gradient sigmoid(x) - t.
+        // log1p(e) = e - e^2/2 + ... for tiny e (1 + e would round it away), hardware log otherwise
+        const float e = __expf(-fabsf(r));
+        const float inv = __builtin_amdgcn_rcpf(1.f + e);
+        l = fmaxf(r, 0.f) - r * t + (e < 1e-4f ? e - 0.5f * e * e : __logf(1.f + e));
+        const float sg = r >= 0.f ? inv : e * inv;
         g = (sg - t) * gs;
     }
 }
@@ -169,6 +174,8 @@ extern "C" int vae_recon_loss_fwd_bwd(const float* recon, const float* target, f
 // run with the partials in a fixed array that is part of the library's code object.  Each GPU holds its own copy of the
 // array at its own address; the address is looked up once per device (hipGetSymbolAddress) and only that device pointer
 // is ever handed to a kernel -- the array's name in host code is a host-side stand-in, not a device address.
+// The first call on a device does that lookup (it may load the code object): under HIP graph capture, make one
+// call on the device BEFORE the capture begins -- any later call only enqueues two kernels.
 #define VAE_STATIC_PARTIALS 16384
 static __device__ __align__(256) float scratch[VAE_STATIC_PARTIALS];
 

@@ -50,6 +50,9 @@ struct ParamLayout {
 
 inline int make_dims(const vae_model_cfg* c, Dims* d, const char* who) {
     CHECK(c, "%s: null config", who);
+    CHECK(c->struct_size == sizeof(vae_model_cfg),
+          "%s: vae_model_cfg.struct_size=%u but this library's struct is %zu bytes (ABI revision %d): the caller was built "
+          "against another revision of include/vae_hip.h", who, c->struct_size, sizeof(vae_model_cfg), VAE_HIP_VERSION);
     CHECK(c->batch > 0, "%s: batch must be > 0 (got %d)", who, c->batch);
     CHECK(c->in_channels >= 1 && c->in_channels <= 8, "%s: in_channels=%d not supported (1..8)", who, c->in_channels);
     CHECK(c->out_channels >= 1 && c->out_channels <= 4, "%s: out_channels=%d not supported (1..4)", who, c->out_channels);

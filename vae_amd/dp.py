@@ -12,10 +12,33 @@ so its buckets are plain views (no copy) and are all-reduced on the process grou
 while the next stage computes."""
 from __future__ import annotations
 
+import os
 from typing import List, Sequence, Tuple
+
+# RCCL shares device buffers between the ranks of a node through dmabuf handles; with the legacy IPC mode the first
+# collective fails with "hipIpcGetMemHandle: invalid argument" on hosts whose driver only supports dmabuf.  It is read
+# when the HIP runtime starts, i.e. before the first GPU call of the process: import this module (or set the variable
+# in the launcher's environment) before touching the GPU.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch
 import torch.distributed as dist
+
+
+def init_process_group(backend: str = "nccl", local_rank: int | None = None, **kw):
+    """torch.distributed.init_process_group for one process per GPU: picks the GPU from LOCAL_RANK (torchrun's
+    variable), binds the RCCL communicator to it and returns (rank, world_size, device).  Rendezvous address and
+    port come from MASTER_ADDR / MASTER_PORT as usual (use 127.0.0.1 on a single node)."""
+    if local_rank is None:
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        dist.init_process_group("nccl", device_id=dev, **kw)
+    else:
+        dev = torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1)) if torch.cuda.is_available() else torch.device("cpu")
+        dist.init_process_group(backend, **kw)
+    return dist.get_rank(), dist.get_world_size(), dev
 
 
 def stage_ranges(offsets: Sequence[Tuple[int, int]], total: int) -> List[Tuple[int, int]]:

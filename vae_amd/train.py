@@ -219,7 +219,6 @@ class FusedStep:
                 m.backward_raw(state, d_recon, None, None, kl_scale, stage)
                 self.reducer.stage_done(stage)
             self.reducer.wait()
-        m._release_workspace(state["batch"], state["ws"])
         if self._grad_views is None or self._grad_views[0].data_ptr() != m.flat_grads.data_ptr():
             self._grad_views = m.grad_views()
         if hasattr(self.optimizer, "step_flat"):
@@ -230,6 +229,9 @@ class FusedStep:
             torch.nn.utils.clip_grad_norm_(m.parameters(), max_norm=self.max_norm)
             self.optimizer.step()
             m.repack_weights()        # the torch optimizer wrote the fp32 parameters: refresh the bf16 operand copies
+        # only now: the optimizer's first launch reads the KL partial sums out of this workspace (`elbo`), so the buffer
+        # must not go back to the pool (where the next forward of any caller would take it) before that launch is queued
+        m._release_workspace(state["batch"], state["ws"])
         return out3[0]
 
 
@@ -249,6 +251,7 @@ def fit(model, optimizer, config, train_feed, val_feed, log=None, checkpoint_pat
     autograd ``train_step``."""
     import torch.distributed as dist
     from .data import save_checkpoint
+    from .dp import sync_bn_stats
     multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
     step = FusedStep(model, optimizer, config, reducer) if fused else None
     best_val_loss = float("inf")
@@ -262,14 +265,19 @@ def fit(model, optimizer, config, train_feed, val_feed, log=None, checkpoint_pat
         model.train()
         losses = [(step(x) if fused else train_step(model, optimizer, x, config)).clone() for x in batches(train_feed)]
         train_epoch_loss = float(torch.stack(losses).sum()) / max(len(losses), 1)
+        if multi:
+            # BatchNorm batch statistics are per rank, so the running statistics drift apart during the epoch: average
+            # them over the ranks first, so that every rank validates -- and rank 0 saves -- the SAME model
+            sync_bn_stats(model)
         model.eval()
         with torch.no_grad():
             losses = [val_step(model, x, config).clone() for x in batches(val_feed)]
         val_epoch_loss = float(torch.stack(losses).sum()) / max(len(losses), 1) if losses else float("nan")
         if multi:
-            # Data-parallel ranks see different validation shards and their BatchNorm running statistics drift
-            # apart (batch statistics are per rank).  The epoch losses become the mean over ranks, so every rank
-            # takes the same "improved" decision, and ONE rank writes the file (with its own running statistics).
+            # Data-parallel ranks see different validation shards.  The epoch losses become the mean over ranks, so
+            # every rank takes the same "improved" decision, and ONE rank writes the file: parameters are replicated
+            # and the running statistics were averaged before the validation pass, so the file is the model whose
+            # loss was compared.
             t = torch.tensor([train_epoch_loss, val_epoch_loss], dtype=torch.float64,
                              device=next(model.parameters()).device)
             dist.all_reduce(t)
