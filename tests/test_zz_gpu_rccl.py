@@ -56,3 +56,28 @@ def test_reducer_over_rccl_is_the_identity_at_world_size_one():
             assert torch.equal(la, lb) and torch.equal(pa, pb), (side_stream, merge_first)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_data_parallel_step_stays_on_the_single_process_loss_curve():
+    """300 steps of the bf16 run of tests/test_gpu_elbo_match.py through the bucketed reducer of a one-rank RCCL group
+    (exchange forced on): the same losses and the same validation loss, bit for bit -- the data-parallel step is on
+    the curve that test compares with the fp32 mode."""
+    from tools_elbo_match import run_curve
+    from vae_amd.dp import BucketedReducer, stage_ranges
+    if dist.is_initialized():
+        pytest.skip("a default process group already exists in this process")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        def reducer(m):
+            red = BucketedReducer(m.flat_grads, stage_ranges(m._offsets, m.flat_grads.numel()))
+            red.world = 2          # force the exchange although there is nobody to exchange with
+            return red
+        la, va = run_curve("bf16", "l1", 300, 128)
+        lb, vb = run_curve("bf16", "l1", 300, 128, reducer_factory=reducer)
+        assert torch.isfinite(la).all() and float(la[-20:].mean()) < float(la[:20].mean())
+        assert torch.equal(la, lb) and va == vb
+    finally:
+        dist.destroy_process_group()
