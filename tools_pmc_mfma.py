@@ -37,7 +37,7 @@ def main():
                   "tflops": a["SQ_VALU_MFMA_BUSY_CYCLES"] / 16 * 16384 / a["ns"] / 1e3}
     json.dump({"note": "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * duration * 2.4 GHz); 16 busy cycles per "
                        "v_mfma_f32_16x16x32_bf16; tflops = MFMAs * 16384 flop / duration (padded tiles included)",
-               "workload": "python3 bench.py --steps 3 --warmup 2 (cfg2: batch 512, 32x32)", "kernels": out},
+               "workload": f"python3 bench.py --config {sys.argv[4] if len(sys.argv) > 4 else 'cfg2_1gpu'} --steps 3 --warmup 2", "kernels": out},
               open(sys.argv[3], "w"), indent=1)
     for k, v in sorted(out.items(), key=lambda kv: -kv[1]["avg_us"] * kv[1]["launches_profiled"]):
         print(f"{k:52s} n={v['launches_profiled']:3d} {v['avg_us']:7.1f} us  util {100 * v['mfma_util']:5.1f} %  {v['tflops']:6.0f} TF")

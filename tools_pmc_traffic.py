@@ -70,7 +70,7 @@ def main():
         out[k]["hbm_bytes_per_launch"] = out[k]["fetch_bytes_per_launch"] + out[k]["write_bytes_per_launch"]
     json.dump({"note": "bytes per launch = 1024 * (2 * FETCH_SIZE + WRITE_SIZE), rocprofv3 --pmc, separate passes; "
                        "FETCH_SIZE doubled for gfx950's 64-byte tally of 128-byte requests",
-               "workload": "python3 bench.py --steps 5 --warmup 2 (cfg2: batch 512, 32x32)", "kernels": out},
+               "workload": f"python3 bench.py --config {sys.argv[4] if len(sys.argv) > 4 else 'cfg2_1gpu'} --steps 5 --warmup 2", "kernels": out},
               open(sys.argv[3], "w"), indent=1)
     for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:12]:
         print(f"{k:40s} {v['hbm_bytes_per_launch'] / 1e6:9.1f} MB/launch (read {v['fetch_bytes_per_launch'] / 1e6:7.1f}, "

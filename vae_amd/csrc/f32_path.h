@@ -34,25 +34,29 @@ struct Gemm {
     int Ci, Co, ks;        // ks: 3 or 1 (conv modes)
     int epi;               // forward modes
     int accumulate;        // dgrad modes: out += result
-    float* slab;           // weight-gradient modes: split-K scratch of slab_need() floats
+    float* slab;           // split-K scratch of slab_need() floats (8-byte aligned; null where slab_need() is 0)
 };
-// floats of split-K scratch the weight-gradient modes need for this geometry (0 for the other modes)
+// floats of split-K scratch this geometry needs (0 when its output tiles fill the chip without a split)
 long slab_need(int mode, int n_img, int H, int W, int Ci, int Co, int ks);
 int gemm(int mode, const Gemm& g, hipStream_t s);
 
 // BatchNorm2d statistics of y [n][C][HW] -> coef: scale[C] | shift[C] | mean[C] | rstd[C] (each `coef_stride` floats
 // apart); train: batch statistics, running stats move (momentum, unbiased variance); else running stats are used
 int bn_stats(const float* y, int n_img, int C, int HW, const float* gamma, const float* beta, float* running_mean,
-             float* running_var, int train, float momentum, float eps, float* coef, int coef_stride, hipStream_t s);
+             float* running_var, int train, float momentum, float eps, float* coef, int coef_stride, double* part,
+             hipStream_t s);
 // out = [maxpool2] dropout(relu(y * scale + shift)); argmax (pooled only): window position 0..3 of the maximum
 int bn_act_fwd(const float* y, const float* coef, int coef_stride, float* out, unsigned char* argmax, int n_img, int C,
                int H, int W, int pool, const DropCfg& drop, hipStream_t s);
 // g = d loss / d out -> dy (= d loss / d y), d gamma, d beta; sums: 2 * C floats of scratch
 int bn_act_bwd(const float* g, const float* y, const float* coef, int coef_stride, const float* gamma,
-               const unsigned char* argmax, float* dy, float* dgamma, float* dbeta, float* sums, int n_img, int C, int H,
-               int W, int pool, const DropCfg& drop, hipStream_t s);
+               const unsigned char* argmax, float* dy, float* dgamma, float* dbeta, float* sums, double* part, int n_img, int C,
+               int H, int W, int pool, const DropCfg& drop, hipStream_t s);
 // out[c] = sum over images and positions of t [n][C][HW] (bias gradients; HW = 1: column sums of a matrix)
-int chan_sum(const float* t, int n_img, int C, int HW, float* out, hipStream_t s);
+int chan_sum(const float* t, int n_img, int C, int HW, float* out, double* part, hipStream_t s);
+// `part`: scratch of chan_part_doubles(C) doubles for the two-stage per-channel reductions above (one workgroup per
+// (channel, share of the images), then one thread per channel)
+long chan_part_doubles(int C);
 int tanh_bwd(const float* dh, const float* h, float* dpre, long n, hipStream_t s);        // dpre = dh * (1 - h^2)
 int sigmoid_bwd(const float* dr, const float* r, float* dpre, long n, hipStream_t s);     // dpre = dr * r * (1 - r)
 

@@ -1,7 +1,8 @@
 // fp32 execution mode: see f32_path.h.  Every layer of the model that is a sum of products runs through ONE tiled
-// kernel (64 x 64 outputs per workgroup, 16-deep K steps through LDS, 4 x 4 outputs per thread) whose operands are
-// fetched by per-mode index maps straight from the NCHW tensors and the parameters' own layouts; the products of
-// fp32 operands are exact in fp64 and are summed there, so a result carries one fp32 rounding whatever K is.
+// kernel (64 x 64 outputs per workgroup, 16-deep K steps through LDS, one 32 x 32 block per wave on the fp32 matrix
+// instruction) whose operands are fetched by per-mode index maps straight from the NCHW tensors and the parameters'
+// own layouts; products are exact; the forward modes sum them in fp64 (the fp64 matrix instruction), the gradient
+// modes in fp32 over blocks of 2048 values of k and in fp64 across the blocks.
 #include "f32_path.h"
 #include "prof.h"
 
@@ -16,6 +17,7 @@ struct G32 {
     int M, N, K, kchunk;
     int n_img, H, W, Ci, Co, ks, pad;
     int epi, accumulate;
+    double* slab;      // split-K partial sums (null: one split, results go straight to `out`)
 };
 
 // which index of an operand tile runs fastest in memory: the loads of a tile are spread over the threads accordingly
@@ -42,7 +44,7 @@ __device__ __forceinline__ Pix pix_of(const G32& g, int p) {
 }
 __device__ __forceinline__ float at4(const float* t, int n, int C, int c, int H, int W, int h, int w) {
     if ((unsigned)h >= (unsigned)H || (unsigned)w >= (unsigned)W) return 0.f;
-    return t[(((long)n * C + c) * H + h) * W + w];
+    return t[((n * C + c) * H + h) * W + w];          // 32-bit index: the launcher checks that every tensor has < 2^31 elements
 }
 // k -> (channel, kernel row, kernel column) of a KS x KS kernel; KS is a compile-time constant, so the divisions
 // are multiplications
@@ -70,47 +72,47 @@ __device__ __forceinline__ float load_a(const G32& g, int m, int k, const Pix& p
         return at4(g.a, pm.n, g.Co, co, g.H, g.W, pm.h + g.pad - kh, pm.w + g.pad - kw);
     } else if constexpr (MODE == CONV_WGRAD) {
         const Pix p = pix_of(g, k);
-        return g.a[(((long)p.n * g.Co + m) * g.H + p.h) * g.W + p.w];
+        return g.a[((p.n * g.Co + m) * g.H + p.h) * g.W + p.w];
     } else if constexpr (MODE == CONVT_FWD) {
-        return g.a[(((long)pm.n * g.Ci + k) * g.H + pm.h) * g.W + pm.w];
+        return g.a[((pm.n * g.Ci + k) * g.H + pm.h) * g.W + pm.w];
     } else if constexpr (MODE == CONVT_DGRAD) {
         const int co = k >> 2, kh = (k >> 1) & 1, kw = k & 1;
-        return g.a[(((long)pm.n * g.Co + co) * (2 * g.H) + 2 * pm.h + kh) * (2 * g.W) + 2 * pm.w + kw];
+        return g.a[((pm.n * g.Co + co) * (2 * g.H) + 2 * pm.h + kh) * (2 * g.W) + 2 * pm.w + kw];
     } else if constexpr (MODE == CONVT_WGRAD) {
         const Pix p = pix_of(g, k);
-        return g.a[(((long)p.n * g.Ci + m) * g.H + p.h) * g.W + p.w];
+        return g.a[((p.n * g.Ci + m) * g.H + p.h) * g.W + p.w];
     } else if constexpr (MODE == LIN_FWD || MODE == LIN_DGRAD) {
-        return g.a[(long)m * g.K + k];
+        return g.a[m * g.K + k];
     } else {   // LIN_WGRAD: dy [K rows][M]
-        return g.a[(long)k * g.M + m];
+        return g.a[k * g.M + m];
     }
 }
 
 template <int MODE, int KS>
 __device__ __forceinline__ float load_b(const G32& g, int k, int n) {
     if constexpr (MODE == CONV_FWD) {
-        return g.b[(long)n * g.K + k];
+        return g.b[n * g.K + k];
     } else if constexpr (MODE == CONV_DGRAD) {
         constexpr int KS2 = KS * KS;
         const int co = k / KS2, t = k - co * KS2;
-        return g.b[((long)co * g.Ci + n) * KS2 + t];
+        return g.b[(co * g.Ci + n) * KS2 + t];
     } else if constexpr (MODE == CONV_WGRAD) {
         const Pix p = pix_of(g, k);
         int ci, kh, kw;
         tap_of<KS>(n, ci, kh, kw);
         return at4(g.b, p.n, g.Ci, ci, g.H, g.W, p.h + kh - g.pad, p.w + kw - g.pad);
     } else if constexpr (MODE == CONVT_FWD) {
-        return g.b[(long)k * g.N + n];
+        return g.b[k * g.N + n];
     } else if constexpr (MODE == CONVT_DGRAD) {
-        return g.b[(long)n * g.K + k];
+        return g.b[n * g.K + k];
     } else if constexpr (MODE == CONVT_WGRAD) {
         const Pix p = pix_of(g, k);
         const int co = n >> 2, kh = (n >> 1) & 1, kw = n & 1;
-        return g.b[(((long)p.n * g.Co + co) * (2 * g.H) + 2 * p.h + kh) * (2 * g.W) + 2 * p.w + kw];
+        return g.b[((p.n * g.Co + co) * (2 * g.H) + 2 * p.h + kh) * (2 * g.W) + 2 * p.w + kw];
     } else if constexpr (MODE == LIN_FWD) {
-        return g.b[(long)n * g.K + k];
+        return g.b[n * g.K + k];
     } else {   // LIN_DGRAD: weight [K][N]; LIN_WGRAD: x [K rows][N]
-        return g.b[(long)k * g.N + n];
+        return g.b[k * g.N + n];
     }
 }
 
@@ -141,85 +143,166 @@ __device__ __forceinline__ void store_c(const G32& g, int m, int n, double acc, 
     } else if constexpr (MODE == LIN_DGRAD) {
         float* o = g.out + (long)m * g.N + n;
         *o = g.accumulate ? (float)((double)*o + acc) : (float)acc;
-    } else {   // weight gradients: split z of the K range -> its own [M][N] slab (or the gradient itself, one split)
-        g.out[(long)z * g.M * g.N + (long)m * g.N + n] = (float)acc;
+    } else {   // weight gradients: [M][N] is the parameter's own layout
+        g.out[(long)m * g.N + n] = (float)acc;
     }
 }
 
 constexpr int TM = 64, TN = 64, TK = 16, LDT = 68;     // tile; LDS row stride (floats)
+constexpr int EPT = TM * TK / 256;                     // operand elements a thread fetches per tile and step
 
 template <int MODE> struct MIsPixel { static constexpr bool value = MODE == CONV_FWD || MODE == CONV_DGRAD || MODE == CONVT_FWD || MODE == CONVT_DGRAD; };
 
+// Lanes of the matrix instruction's result run along the index that is contiguous in the output tensor: the pixel (m)
+// for the NCHW activations of the forward / input-gradient modes, the column (n) for row-major results.
+template <int MODE> struct LanesAlongM { static constexpr bool value = MIsPixel<MODE>::value; };
+
+// Which matrix instruction sums the products.
+//   Forward modes: v_mfma_f64_16x16x4_f64 on operands widened to fp64 -- products of fp32 values are exact in fp64 and
+//   the sum carries ~1e-16 per step, so a result is the correctly rounded fp32 value of the exact sum (but for ties
+//   in the 29 bits below).  The forward pass needs that: its values decide ReLU, max-pool and sign(recon - x)
+//   routes, and an activation that sits within fp32 summation noise of such a decision flips gradients in front of it
+//   by 1e-3.  The exact sum is what every order of fp32 summation scatters around, so it takes the decision most
+//   fp32 runs of the reference take.
+//   Backward modes (input and weight gradients): v_mfma_f32_32x32x2_f32 -- exact fp32 products accumulated in fp32
+//   (bitwise an fmaf chain) at twice the fp64 instruction's rate.  Every KBLOCK values of k the fp32 accumulators are
+//   added into fp64 ones and cleared, so the rounding error does not grow with K (5e5 in a weight gradient): a
+//   block's fp32 sum is off by ~1e-7 of sum |a b|, and the blocks combine in fp64 in a fixed order.  Nothing decides
+//   anything on these values: the error stays ~1e-6 relative, inside the 2e-5 figure on gradients.
+template <int MODE> struct ExactSum { static constexpr bool value = MODE == CONV_FWD || MODE == CONVT_FWD || MODE == LIN_FWD; };
+constexpr int KBLOCK = 2048;
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) double f64x4;
+
 template <int MODE, int KS>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const G32 g) {
-    // (tiles staged as fp64 -- one conversion per operand instead of one per product -- measured slower: 7.6 vs 10.3
-    // TFLOP/s, the doubled LDS reads cost more than the conversions)
     __shared__ __attribute__((aligned(16))) float As[TK][LDT];
     __shared__ __attribute__((aligned(16))) float Bs[TK][LDT];
-    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;                     // wave tile: rows [32 wm, +32) x columns [32 wn, +32)
     const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN, z = blockIdx.z;
     const int kbeg = z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
     // the tile rows / columns this thread fetches are the same in every K step: (mm[i], kk[i]) of A, (nn[i], kb[i]) of B
-    int mm[4], ka[4], nn[4], kb[4];
-    Pix pm[4];
+    int mm[EPT], ka[EPT], nn[EPT], kb[EPT];
+    Pix pm[EPT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (Traits<MODE>::a_kfast) { ka[i] = tid & 15; mm[i] = (tid >> 4) + 16 * i; }
+    for (int i = 0; i < EPT; ++i) {
+        if (Traits<MODE>::a_kfast) { ka[i] = tid % TK; mm[i] = tid / TK + (256 / TK) * i; }
         else { mm[i] = tid & 63; ka[i] = (tid >> 6) + 4 * i; }
-        if (Traits<MODE>::b_kfast) { kb[i] = tid & 15; nn[i] = (tid >> 4) + 16 * i; }
+        if (Traits<MODE>::b_kfast) { kb[i] = tid % TK; nn[i] = tid / TK + (256 / TK) * i; }
         else { nn[i] = tid & 63; kb[i] = (tid >> 6) + 4 * i; }
         pm[i] = Pix{0, 0, 0};
         if (MIsPixel<MODE>::value && m0 + mm[i] < g.M) pm[i] = pix_of(g, m0 + mm[i]);
     }
-    double acc[4][4];
+    constexpr bool LM = LanesAlongM<MODE>::value, EXACT = ExactSum<MODE>::value;
+    // fp32 instruction: one 32 x 32 block per wave, lane -> (row / column lane & 31, k = lane >> 5)
+    f32x16 acc;
+    double accd[16];
+    // fp64 instruction: 2 x 2 blocks of 16 x 16 per wave, lane -> (row / column lane & 15, k = lane >> 4)
+    f64x4 dacc[2][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accd[r] = 0.0; }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
-    for (int k0 = kbeg; k0 < kend; k0 += TK) {
-        float av[4], bv[4];
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {       // all eight loads of a step are requested before any is stored
+        for (int j = 0; j < 2; ++j) dacc[i][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    const float* ap = EXACT ? &As[lane >> 4][wm * 32 + (lane & 15)] : &As[lane >> 5][wm * 32 + (lane & 31)];
+    const float* bp = EXACT ? &Bs[lane >> 4][wn * 32 + (lane & 15)] : &Bs[lane >> 5][wn * 32 + (lane & 31)];
+    int since = 0;
+    float av[EPT], bv[EPT];
+    auto fetch = [&](int k0) {              // all the loads of a step are requested together
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
             av[i] = (m0 + mm[i] < g.M && k0 + ka[i] < kend) ? load_a<MODE, KS>(g, m0 + mm[i], k0 + ka[i], pm[i]) : 0.f;
             bv[i] = (n0 + nn[i] < g.N && k0 + kb[i] < kend) ? load_b<MODE, KS>(g, k0 + kb[i], n0 + nn[i]) : 0.f;
         }
+    };
+    if (kbeg < kend) fetch(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += TK) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < EPT; ++i) {
             As[ka[i]][mm[i]] = av[i];
             Bs[kb[i]][nn[i]] = bv[i];
         }
         __syncthreads();
+        if (k0 + TK < kend) fetch(k0 + TK);     // the next step's operands travel while this step is multiplied
+        if constexpr (EXACT) {
 #pragma unroll
-        for (int kk = 0; kk < TK; ++kk) {
-            const float4 a4 = *(const float4*)&As[kk][ty * 4];
-            const float4 b4 = *(const float4*)&Bs[kk][tx * 4];
-            const double a[4] = {a4.x, a4.y, a4.z, a4.w}, b[4] = {b4.x, b4.y, b4.z, b4.w};
+            for (int kk = 0; kk < TK / 4; ++kk) {
+                const double a[2] = {(double)ap[4 * kk * LDT], (double)ap[4 * kk * LDT + 16]};
+                const double b[2] = {(double)bp[4 * kk * LDT], (double)bp[4 * kk * LDT + 16]};
+                // result[i][j] = sum_k first[i][k] * second[k][j]; lanes run along j
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = fma(a[i], b[j], acc[i][j]);
+                    for (int j = 0; j < 2; ++j)
+                        dacc[i][j] = LM ? __builtin_amdgcn_mfma_f64_16x16x4f64(b[i], a[j], dacc[i][j], 0, 0, 0)
+                                        : __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], dacc[i][j], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < TK / 2; ++kk) {
+                const float a = ap[2 * kk * LDT], b = bp[2 * kk * LDT];
+                acc = LM ? __builtin_amdgcn_mfma_f32_32x32x2f32(b, a, acc, 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            }
+            since += TK;
+            if (since >= KBLOCK) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { accd[r] += (double)acc[r]; acc[r] = 0.f; }
+                since = 0;
+            }
         }
         __syncthreads();
     }
+    // one split: the result itself; several: this split's partial sums (fp64, the index the lanes run along fastest)
+    auto put = [&](int m, int n, double v) {
+        if (m >= g.M || n >= g.N) return;
+        if (g.slab) g.slab[(long)z * g.M * g.N + (LM ? (long)n * g.M + m : (long)m * g.N + n)] = v;
+        else store_c<MODE>(g, m, n, v, 0);
+    };
+    if constexpr (EXACT) {
+        // register r of block (bi, bj): row 16 bi + (lane >> 4) + 4 r, column 16 bj + (lane & 15)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int bi = 0; bi < 2; ++bi)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
-            if (m < g.M && n < g.N) store_c<MODE>(g, m, n, acc[i][j], z);
+            for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * bi + (lane >> 4) + 4 * r, j = 16 * bj + (lane & 15);
+                    put(m0 + wm * 32 + (LM ? j : i), n0 + wn * 32 + (LM ? i : j), dacc[bi][bj][r]);
+                }
+    } else {
+        // register r of the 32 x 32 result: row i = 8 (r / 4) + 4 (lane / 32) + r % 4, column j = lane % 32
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3), j = lane & 31;
+            put(m0 + wm * 32 + (LM ? j : i), n0 + wn * 32 + (LM ? i : j), accd[r] + (double)acc[r]);
         }
+    }
 }
 
-// out[i] = sum over the splits of slab[z][i], in split order, in fp64
-__global__ __launch_bounds__(256) void fold_f32_kernel(const float* __restrict__ slab, int nsplit, long n, float* __restrict__ out) {
+// result element (m, n) = sum over the splits of their partial sums, in split order, in fp64, then the mode's own
+// epilogue and store.  Threads run along the index that is fastest in the slabs (and in the output).
+template <int MODE>
+__global__ __launch_bounds__(256) void fold_store_kernel(const G32 g, int nsplit) {
+    constexpr bool LM = LanesAlongM<MODE>::value;
+    const long total = (long)g.M * g.N;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    double s = 0.0;
-    for (int z = 0; z < nsplit; ++z) s += (double)slab[(long)z * n + i];
-    out[i] = (float)s;
+    if (i >= total) return;
+    // four independent chains keep four loads in flight (one chain is a latency ladder of `nsplit` round trips);
+    // the grouping is fixed, so the sum is reproducible
+    double s4[4] = {0.0, 0.0, 0.0, 0.0};
+    int z = 0;
+    for (; z + 3 < nsplit; z += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s4[u] += g.slab[(long)(z + u) * total + i];
+    }
+    for (; z < nsplit; ++z) s4[0] += g.slab[(long)z * total + i];
+    const double s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+    const int m = LM ? (int)(i % g.M) : (int)(i / g.N), n = LM ? (int)(i / g.M) : (int)(i % g.N);
+    store_c<MODE>(g, m, n, s, 0);
 }
-
-static bool is_wgrad(int mode) { return mode == CONV_WGRAD || mode == CONVT_WGRAD || mode == LIN_WGRAD; }
 
 static void mnk(int mode, int n_img, int H, int W, int Ci, int Co, int ks, long* M, long* N, long* K) {
     const long pix = (long)n_img * H * W;
@@ -236,25 +319,27 @@ static void mnk(int mode, int n_img, int H, int W, int Ci, int Co, int ks, long*
     }
 }
 
-// split the K range of a weight gradient so that about 1024 workgroups run; chunks are multiples of 16 of at least 256
-static int wgrad_splits(long M, long N, long K, int* kchunk) {
+// Split the K range so that about 1024 workgroups run when the output has few tiles (weight gradients: K is the pixel
+// count; at small batches also the 4x4 / 8x8 layers and the Linear layers, whose 2-64 output tiles would each walk
+// thousands of k alone).  Chunks are multiples of the K step of at least 128.
+static int k_splits(long M, long N, long K, int* kchunk) {
     const long tiles = ((M + TM - 1) / TM) * ((N + TN - 1) / TN);
-    long want = (1024 + tiles - 1) / tiles;
-    const long most = (K + 255) / 256;
+    long want = tiles >= 512 ? 1 : (1024 + tiles - 1) / tiles;
+    const long most = (K + 127) / 128;
     if (want > most) want = most;
     if (want < 1) want = 1;
-    long chunk = ((K + want - 1) / want + 15) / 16 * 16;
+    long chunk = ((K + want - 1) / want + TK - 1) / TK * TK;
     *kchunk = (int)chunk;
     return (int)((K + chunk - 1) / chunk);
 }
 
+// scratch for the fp64 partial sums of a split GEMM, in floats (two per partial sum)
 long slab_need(int mode, int n_img, int H, int W, int Ci, int Co, int ks) {
-    if (!is_wgrad(mode)) return 0;
     long M, N, K;
     mnk(mode, n_img, H, W, Ci, Co, ks, &M, &N, &K);
     int kchunk;
-    const int ns = wgrad_splits(M, N, K, &kchunk);
-    return ns > 1 ? (long)ns * M * N : 0;
+    const int ns = k_splits(M, N, K, &kchunk);
+    return ns > 1 ? 2L * ns * M * N : 0;
 }
 
 int gemm(int mode, const Gemm& q, hipStream_t s) {
@@ -267,26 +352,32 @@ int gemm(int mode, const Gemm& q, hipStream_t s) {
     long M, N, K;
     mnk(mode, q.n_img, q.H, q.W, q.Ci, q.Co, q.ks, &M, &N, &K);
     VAE_CHECK(M < (1L << 31) && N < (1L << 31) && K < (1L << 31), "f32 gemm: a dimension exceeds 2^31");
+    // the operand index maps run in 32-bit arithmetic: no operand tensor may reach 2^31 elements (the largest
+    // activation is [n][max(Ci, Co)][2H][2W], a ConvTranspose's output; the largest weight Co x Ci x 9)
+    VAE_CHECK((long)q.n_img * q.H * q.W * 4 * (q.Ci > q.Co ? q.Ci : q.Co) < (1L << 31) && (long)q.Ci * q.Co * 9 < (1L << 31),
+              "f32 gemm: an operand has 2^31 elements or more (n=%d H=%d W=%d Ci=%d Co=%d)", q.n_img, q.H, q.W, q.Ci, q.Co);
     G32 g = {};
     g.a = q.a; g.b = q.b; g.bias = q.bias; g.out = q.out;
     g.M = (int)M; g.N = (int)N; g.K = (int)K;
     g.n_img = q.n_img; g.H = q.H; g.W = q.W; g.Ci = q.Ci; g.Co = q.Co; g.ks = conv ? q.ks : 1; g.pad = g.ks / 2;
     g.epi = q.epi; g.accumulate = q.accumulate;
-    int splits = 1;
-    g.kchunk = (int)((K + 15) / 16 * 16);
-    float* final_out = q.out;
-    if (is_wgrad(mode)) {
-        splits = wgrad_splits(M, N, K, &g.kchunk);
-        if (splits > 1) {
-            VAE_CHECK(q.slab, "f32 gemm: weight gradient needs %ld floats of split-K scratch", (long)splits * M * N);
-            g.out = q.slab;
-        }
+    const int splits = k_splits(M, N, K, &g.kchunk);
+    g.slab = nullptr;
+    if (splits > 1) {
+        VAE_CHECK(q.slab, "f32 gemm: this geometry splits K %d ways and needs %ld floats of scratch", splits, 2L * splits * M * N);
+        VAE_CHECK(((uintptr_t)q.slab & 7) == 0, "f32 gemm: the split-K scratch must be 8-byte aligned");
+        g.slab = (double*)q.slab;
     }
     const dim3 grid((unsigned)((M + TM - 1) / TM), (unsigned)((N + TN - 1) / TN), (unsigned)splits);
     VAE_CHECK(grid.y < 65536 && grid.z < 65536, "f32 gemm: grid too large");
+    const dim3 fgrid((unsigned)((M * N + 255) / 256));
     {
         ProfScope prof("gemm_f32_kernel", 2.0 * (double)M * (double)N * (double)K, 0.0, s);
-#define GO(M, K) hipLaunchKernelGGL((gemm_f32_kernel<M, K>), grid, dim3(256), 0, s, g)
+#define GO(MD, KS_)                                                                         \
+        do {                                                                                \
+            hipLaunchKernelGGL((gemm_f32_kernel<MD, KS_>), grid, dim3(256), 0, s, g);       \
+            if (splits > 1) hipLaunchKernelGGL((fold_store_kernel<MD>), fgrid, dim3(256), 0, s, g, splits); \
+        } while (0)
         switch (mode) {
             case CONV_FWD: if (g.ks == 3) GO(CONV_FWD, 3); else GO(CONV_FWD, 1); break;
             case CONV_DGRAD: if (g.ks == 3) GO(CONV_DGRAD, 3); else GO(CONV_DGRAD, 1); break;
@@ -300,11 +391,6 @@ int gemm(int mode, const Gemm& q, hipStream_t s) {
         }
 #undef GO
         VAE_LAUNCH_CHECK("gemm_f32_kernel");
-    }
-    if (splits > 1) {
-        const long n = M * N;
-        hipLaunchKernelGGL(fold_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, q.slab, splits, n, final_out);
-        VAE_LAUNCH_CHECK("fold_f32_kernel");
     }
     return 0;
 }
@@ -321,55 +407,87 @@ __device__ __forceinline__ double block_sum_d(double v, double* red) {      // e
     return r;
 }
 
-__global__ __launch_bounds__(256) void bn_stats_f32_kernel(const float* __restrict__ y, int n_img, int C, int HW,
+// Per-channel reductions over (image, position) run in two stages so that they fill the chip whatever the channel
+// count: grid (C, S) -- workgroup (c, s) sums its contiguous share of the images in fp64 and leaves one partial per
+// quantity -- then one thread per channel adds the S partials in split order.  (One workgroup per channel left 64-256
+// workgroups walking the whole batch: a quarter of the fp32 step.)
+constexpr int MAX_CHAN_SPLIT = 64;
+long chan_part_doubles(int C) { return 2L * (C > 1024 ? C : 1024) + 2L * 256; }
+static int chan_splits(int n_img, int C) {
+    int s = 1024 / C;
+    if (s < 1) s = 1;
+    if (s > n_img) s = n_img;
+    return s > MAX_CHAN_SPLIT ? MAX_CHAN_SPLIT : s;
+}
+__device__ __forceinline__ void split_range(int n_img, int& n0, int& n1) {
+    n0 = (int)((long)blockIdx.y * n_img / gridDim.y);
+    n1 = (int)((long)(blockIdx.y + 1) * n_img / gridDim.y);
+}
+
+__global__ __launch_bounds__(256) void bn_stats_part_kernel(const float* __restrict__ y, int n_img, int C, int HW,
+                                                            double* __restrict__ part) {
+    __shared__ double red[4];
+    const int c = blockIdx.x;
+    int n0, n1;
+    split_range(n_img, n0, n1);
+    double s = 0.0, q = 0.0;
+    for (int n = n0; n < n1; ++n) {
+        const float* p = y + ((long)n * C + c) * HW;
+        for (int i = threadIdx.x; i < HW; i += 256) {
+            const double v = (double)p[i];
+            s += v;
+            q = fma(v, v, q);
+        }
+    }
+    s = block_sum_d(s, red);
+    q = block_sum_d(q, red);
+    if (threadIdx.x == 0) {
+        part[((long)c * gridDim.y + blockIdx.y) * 2] = s;
+        part[((long)c * gridDim.y + blockIdx.y) * 2 + 1] = q;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_stats_fin_kernel(const double* __restrict__ part, int S, double cnt, int C,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            float* running_mean, float* running_var, int train, float momentum,
                                                            float eps, float* coef, int cs) {
-    __shared__ double red[4];
-    const int c = blockIdx.x;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
     double mean, var;
     if (train) {
         double s = 0.0, q = 0.0;
-        for (int n = 0; n < n_img; ++n) {
-            const float* p = y + ((long)n * C + c) * HW;
-            for (int i = threadIdx.x; i < HW; i += 256) {
-                const double v = (double)p[i];
-                s += v;
-                q = fma(v, v, q);
-            }
-        }
-        s = block_sum_d(s, red);
-        q = block_sum_d(q, red);
-        const double cnt = (double)n_img * HW;
+        for (int i = 0; i < S; ++i) { s += part[((long)c * S + i) * 2]; q += part[((long)c * S + i) * 2 + 1]; }
         mean = s / cnt;
         var = q / cnt - mean * mean;
         if (var < 0.0) var = 0.0;
-        if (threadIdx.x == 0) {
-            const double unb = var * (cnt / (cnt > 1.0 ? cnt - 1.0 : 1.0));
-            running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
-            running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unb);
-        }
+        const double unb = var * (cnt / (cnt > 1.0 ? cnt - 1.0 : 1.0));
+        running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
+        running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unb);
     } else {
         mean = (double)running_mean[c];
         var = (double)running_var[c];
     }
-    if (threadIdx.x == 0) {
-        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-        const float sc = gamma[c] * rstd;
-        coef[c] = sc;
-        coef[cs + c] = beta[c] - (float)mean * sc;
-        coef[2 * cs + c] = (float)mean;
-        coef[3 * cs + c] = rstd;
-    }
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[c] * rstd;
+    coef[c] = sc;
+    coef[cs + c] = beta[c] - (float)mean * sc;
+    coef[2 * cs + c] = (float)mean;
+    coef[3 * cs + c] = rstd;
 }
 
 int bn_stats(const float* y, int n_img, int C, int HW, const float* gamma, const float* beta, float* running_mean,
-             float* running_var, int train, float momentum, float eps, float* coef, int coef_stride, hipStream_t s) {
-    VAE_CHECK(y && gamma && beta && running_mean && running_var && coef, "f32 bn_stats: null pointer");
+             float* running_var, int train, float momentum, float eps, float* coef, int coef_stride, double* part,
+             hipStream_t s) {
+    VAE_CHECK(y && gamma && beta && running_mean && running_var && coef && part, "f32 bn_stats: null pointer");
     VAE_CHECK(n_img > 0 && C > 0 && C <= coef_stride && HW > 0, "f32 bn_stats: bad geometry n=%d C=%d HW=%d", n_img, C, HW);
-    hipLaunchKernelGGL(bn_stats_f32_kernel, dim3(C), dim3(256), 0, s, y, n_img, C, HW, gamma, beta, running_mean, running_var,
-                       train, momentum, eps, coef, coef_stride);
-    VAE_LAUNCH_CHECK("bn_stats_f32_kernel");
+    const int S = chan_splits(n_img, C);
+    if (train) {
+        hipLaunchKernelGGL(bn_stats_part_kernel, dim3(C, S), dim3(256), 0, s, y, n_img, C, HW, part);
+        VAE_LAUNCH_CHECK("bn_stats_part_kernel");
+    }
+    hipLaunchKernelGGL(bn_stats_fin_kernel, dim3((C + 255) / 256), dim3(256), 0, s, part, S, (double)n_img * HW, C, gamma, beta,
+                       running_mean, running_var, train, momentum, eps, coef, coef_stride);
+    VAE_LAUNCH_CHECK("bn_stats_fin_kernel");
     return 0;
 }
 
@@ -449,14 +567,16 @@ __device__ __forceinline__ float dpre_at(const float* g, const float* y, float s
 
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_f32_kernel(const float* __restrict__ g, const float* __restrict__ y,
                                                                     const float* __restrict__ coef, int cs,
-                                                                    const unsigned char* __restrict__ argmax, float* dgamma,
-                                                                    float* dbeta, float* sums, int n_img, int C, int H, int W,
+                                                                    const unsigned char* __restrict__ argmax,
+                                                                    double* __restrict__ part, int n_img, int C, int H, int W,
                                                                     int pool, const DropCfg d) {
     __shared__ double red[4];
     const int c = blockIdx.x;
+    int n0, n1;
+    split_range(n_img, n0, n1);
     const float sc = coef[c], sh = coef[cs + c], mean = coef[2 * cs + c], rstd = coef[3 * cs + c];
     double s1 = 0.0, s2 = 0.0;
-    for (int n = 0; n < n_img; ++n)
+    for (int n = n0; n < n1; ++n)
         for (int i = threadIdx.x; i < H * W; i += 256) {
             const int h = i / W, w = i - h * W;
             const float dp = dpre_at(g, y, sc, sh, argmax, d, n, c, h, w, C, H, W, pool);
@@ -469,11 +589,24 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_f32_kernel(const float*
     s1 = block_sum_d(s1, red);
     s2 = block_sum_d(s2, red);
     if (threadIdx.x == 0) {
-        dbeta[c] = (float)s1;
-        dgamma[c] = (float)s2;
-        sums[c] = (float)s1;
-        sums[C + c] = (float)s2;
+        part[((long)c * gridDim.y + blockIdx.y) * 2] = s1;
+        part[((long)c * gridDim.y + blockIdx.y) * 2 + 1] = s2;
     }
+}
+
+// out1[c] = sum of the first partials of channel c, out2[c] (optional) of the second; copies (optional) [C | C]
+__global__ __launch_bounds__(256) void chan_fin_kernel(const double* __restrict__ part, int S, int C, int stride, float* out1,
+                                                       float* out2, float* copies) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double a = 0.0, b = 0.0;
+    for (int i = 0; i < S; ++i) {
+        a += part[((long)c * S + i) * stride];
+        if (stride == 2) b += part[((long)c * S + i) * 2 + 1];
+    }
+    out1[c] = (float)a;
+    if (out2) out2[c] = (float)b;
+    if (copies) { copies[c] = (float)a; copies[C + c] = (float)b; }
 }
 
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_f32_kernel(const float* __restrict__ g, const float* __restrict__ y,
@@ -495,14 +628,18 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_f32_kernel(const float* 
 }
 
 int bn_act_bwd(const float* g, const float* y, const float* coef, int coef_stride, const float* gamma, const unsigned char* argmax,
-               float* dy, float* dgamma, float* dbeta, float* sums, int n_img, int C, int H, int W, int pool, const DropCfg& drop,
-               hipStream_t s) {
-    VAE_CHECK(g && y && coef && gamma && dy && dgamma && dbeta && sums, "f32 bn_act_bwd: null pointer");
+               float* dy, float* dgamma, float* dbeta, float* sums, double* part, int n_img, int C, int H, int W, int pool,
+               const DropCfg& drop, hipStream_t s) {
+    VAE_CHECK(g && y && coef && gamma && dy && dgamma && dbeta && sums && part, "f32 bn_act_bwd: null pointer");
     VAE_CHECK(n_img > 0 && C > 0 && H > 0 && W > 0, "f32 bn_act_bwd: bad geometry");
     VAE_CHECK(!pool || argmax, "f32 bn_act_bwd: the pooled form needs the forward's argmax bytes");
-    hipLaunchKernelGGL(bn_act_bwd_reduce_f32_kernel, dim3(C), dim3(256), 0, s, g, y, coef, coef_stride, argmax, dgamma, dbeta, sums,
-                       n_img, C, H, W, pool, drop);
+    const int S = chan_splits(n_img, C);
+    hipLaunchKernelGGL(bn_act_bwd_reduce_f32_kernel, dim3(C, S), dim3(256), 0, s, g, y, coef, coef_stride, argmax, part, n_img, C, H,
+                       W, pool, drop);
     VAE_LAUNCH_CHECK("bn_act_bwd_reduce_f32_kernel");
+    // d beta = sum(dy_hat), d gamma = sum(dy_hat * x_hat); the apply pass reads both from `sums`
+    hipLaunchKernelGGL(chan_fin_kernel, dim3((C + 255) / 256), dim3(256), 0, s, part, S, C, 2, dbeta, dgamma, sums);
+    VAE_LAUNCH_CHECK("chan_fin_kernel");
     const long total = (long)n_img * C * H * W;
     hipLaunchKernelGGL(bn_act_bwd_apply_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g, y, coef, coef_stride,
                        gamma, argmax, sums, dy, n_img, C, H, W, pool, drop);
@@ -511,22 +648,28 @@ int bn_act_bwd(const float* g, const float* y, const float* coef, int coef_strid
 }
 
 // ---------------------------------------------------------------------------------------------- small pieces
-__global__ __launch_bounds__(256) void chan_sum_f32_kernel(const float* __restrict__ t, int n_img, int C, int HW, float* out) {
+__global__ __launch_bounds__(256) void chan_sum_f32_kernel(const float* __restrict__ t, int n_img, int C, int HW,
+                                                           double* __restrict__ part) {
     __shared__ double red[4];
     const int c = blockIdx.x;
+    int n0, n1;
+    split_range(n_img, n0, n1);
     double s = 0.0;
-    const long per = (long)n_img * HW;
+    const long per = (long)(n1 - n0) * HW;
     for (long i = threadIdx.x; i < per; i += 256) {
-        const long n = i / HW, r = i - n * HW;
+        const long n = n0 + i / HW, r = i % HW;
         s += (double)t[(n * C + c) * HW + r];
     }
     s = block_sum_d(s, red);
-    if (threadIdx.x == 0) out[c] = (float)s;
+    if (threadIdx.x == 0) part[(long)c * gridDim.y + blockIdx.y] = s;
 }
-int chan_sum(const float* t, int n_img, int C, int HW, float* out, hipStream_t s) {
-    VAE_CHECK(t && out && n_img > 0 && C > 0 && HW > 0, "f32 chan_sum: bad arguments");
-    hipLaunchKernelGGL(chan_sum_f32_kernel, dim3(C), dim3(256), 0, s, t, n_img, C, HW, out);
+int chan_sum(const float* t, int n_img, int C, int HW, float* out, double* part, hipStream_t s) {
+    VAE_CHECK(t && out && part && n_img > 0 && C > 0 && HW > 0, "f32 chan_sum: bad arguments");
+    const int S = chan_splits(n_img, C);
+    hipLaunchKernelGGL(chan_sum_f32_kernel, dim3(C, S), dim3(256), 0, s, t, n_img, C, HW, part);
     VAE_LAUNCH_CHECK("chan_sum_f32_kernel");
+    hipLaunchKernelGGL(chan_fin_kernel, dim3((C + 255) / 256), dim3(256), 0, s, part, S, C, 1, out, (float*)nullptr, (float*)nullptr);
+    VAE_LAUNCH_CHECK("chan_fin_kernel");
     return 0;
 }
 

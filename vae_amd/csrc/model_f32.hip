@@ -19,7 +19,7 @@ struct WsF32 {
     long ya[4], aa[4], yb[4], ob[4], arg[3];
     long coef;               // 11 x {scale, shift, mean, rstd} x 256 floats
     long z, klp, h, yd[3], ad[3];
-    long g[2], dhead, slab, sums, dz, dmu, dlv;
+    long g[2], dhead, slab, sums, part, dz, dmu, dlv;
     long slab_floats;
     long total_bytes;
 };
@@ -51,17 +51,25 @@ void make_ws_f32(const Dims& d, WsF32* w) {
         const long v = slab_need(mode, d.N, H, H, Ci, Co, ks);
         if (v > s) s = v;
     };
+    // every GEMM the two passes run (one at a time: the scratch is the largest need)
     for (int b = 0; b < 4; ++b) {
-        need(CONV_WGRAD, d.S >> b, b ? ENC_C[b - 1] : d.Cin, ENC_C[b], 3);
-        need(CONV_WGRAD, d.S >> b, ENC_C[b], ENC_C[b], 3);
+        const int Ci = b ? ENC_C[b - 1] : d.Cin, C = ENC_C[b], H = d.S >> b;
+        for (int mode : {CONV_FWD, CONV_DGRAD, CONV_WGRAD}) {
+            need(mode, H, Ci, C, 3);
+            need(mode, H, C, C, 3);
+        }
     }
-    for (int u = 0; u < 3; ++u) need(CONVT_WGRAD, s8 << u, DEC_CI[u], DEC_CO[u], 1);
-    need(CONV_WGRAD, d.S, 64, d.Cout, 1);
-    need(LIN_WGRAD, 1, d.F, d.L, 1);
-    need(LIN_WGRAD, 1, d.L, d.F, 1);
+    for (int u = 0; u < 3; ++u)
+        for (int mode : {CONVT_FWD, CONVT_DGRAD, CONVT_WGRAD}) need(mode, s8 << u, DEC_CI[u], DEC_CO[u], 1);
+    for (int mode : {CONV_FWD, CONV_DGRAD, CONV_WGRAD}) need(mode, d.S, 64, d.Cout, 1);
+    for (int mode : {LIN_FWD, LIN_DGRAD, LIN_WGRAD}) {
+        need(mode, 1, d.F, d.L, 1);
+        need(mode, 1, d.L, d.F, 1);
+    }
     w->slab_floats = s;
     w->slab = put((s > 0 ? s : 64) * 4);
     w->sums = put(2 * 256 * 4);
+    w->part = put(chan_part_doubles(d.F) * 8);
     w->dz = put((long)d.N * d.L * 4); w->dmu = put((long)d.N * d.L * 4); w->dlv = put((long)d.N * d.L * 4);
     w->total_bytes = o;
 }
@@ -79,6 +87,7 @@ struct C32 {
     const float* P(int i) const { return params + pl->off[i]; }
     float* G(int i) const { return grads + pl->off[i]; }
     float* F(long off) const { return (float*)(w + off); }
+    double* part() const { return (double*)(w + ws.part); }
     float* coef(int bi) const { return (float*)(w + ws.coef) + (long)bi * 4 * 256; }
     float* rmean(int bi) const { return bn + pl->bn_off[bi]; }
     float* rvar(int bi) const { return bn + pl->bn_off[bi] + pl->bn_c[bi]; }
@@ -98,7 +107,7 @@ DropCfg no_drop() { return make_drop(0.0, nullptr, 0, 0, 0, 0); }
 
 int stats(const C32& c, const float* y, int bi, int g_idx, int HW) {
     return bn_stats(y, c.d.N, c.pl->bn_c[bi], HW, c.P(g_idx), c.P(g_idx + 1), c.rmean(bi), c.rvar(bi), c.cfg->train, 0.1f, 1e-5f,
-                    c.coef(bi), 256, c.s);
+                    c.coef(bi), 256, c.part(), c.s);
 }
 
 int encoder_forward(const C32& c, const float* x, const void* const* masks, float* mu, float* logvar) {
@@ -154,29 +163,29 @@ int backward_decoder(const C32& c, const float* d_recon, const float* recon, con
     // sigmoid + 1x1 head
     TRY(sigmoid_bwd(d_recon, recon, dhead, (long)d.N * d.Cout * d.S * d.S, c.s));
     TRY(run(c, CONV_WGRAD, dhead, c.F(w.ad[2]), nullptr, c.G(P_HEAD_W), d.S, 64, d.Cout, 1));
-    TRY(chan_sum(dhead, d.N, d.Cout, d.S * d.S, c.G(P_HEAD_B), c.s));
+    TRY(chan_sum(dhead, d.N, d.Cout, d.S * d.S, c.G(P_HEAD_B), c.part(), c.s));
     TRY(run(c, CONV_DGRAD, dhead, c.P(P_HEAD_W), nullptr, cur, d.S, 64, d.Cout, 1));
     for (int u = 2; u >= 0; --u) {
         const int hh = s8 << u, ho = 2 * hh, Ci = DEC_CI[u], Co = DEC_CO[u];
         const int gi = P_BN3_G + 4 * u;
-        TRY(bn_act_bwd(cur, c.F(w.yd[u]), c.coef(8 + u), 256, c.P(gi), nullptr, other, c.G(gi), c.G(gi + 1), sums, d.N, Co, ho, ho, 0,
+        TRY(bn_act_bwd(cur, c.F(w.yd[u]), c.coef(8 + u), 256, c.P(gi), nullptr, other, c.G(gi), c.G(gi + 1), sums, c.part(), d.N, Co, ho, ho, 0,
                        no_drop(), c.s));
-        TRY(chan_sum(other, d.N, Co, ho * ho, c.G(P_UP3_B + 4 * u), c.s));
+        TRY(chan_sum(other, d.N, Co, ho * ho, c.G(P_UP3_B + 4 * u), c.part(), c.s));
         const float* xin = u == 0 ? c.F(w.h) : c.F(w.ad[u - 1]);
         TRY(run(c, CONVT_WGRAD, xin, other, nullptr, c.G(P_UP3_W + 4 * u), hh, Ci, Co, 1));
         TRY(run(c, CONVT_DGRAD, other, c.P(P_UP3_W + 4 * u), nullptr, cur, hh, Ci, Co, 1));
     }
     // cur = d tanh(fc_up(z)) [N][F]
     TRY(tanh_bwd(cur, c.F(w.h), other, (long)d.N * d.F, c.s));
-    TRY(chan_sum(other, d.N, d.F, 1, c.G(P_FC_UP_B), c.s));
+    TRY(chan_sum(other, d.N, d.F, 1, c.G(P_FC_UP_B), c.part(), c.s));
     TRY(run(c, LIN_WGRAD, other, c.F(w.z), nullptr, c.G(P_FC_UP_W), 1, d.L, d.F, 1));
     TRY(run(c, LIN_DGRAD, other, c.P(P_FC_UP_W), nullptr, c.F(w.dz), 1, d.L, d.F, 1));
     float* dmu = c.F(w.dmu);
     float* dlv = c.F(w.dlv);
     TRY(vae_reparam_kl_bwd(c.F(w.dz), mu, logvar, eps_in, dmu_ext, dlv_ext, kl_scale, dmu, dlv, nullptr, (long)d.N * d.L, d.L,
                            c.cfg->seed, c.cfg->step, c.cfg->rank, c.s));
-    TRY(chan_sum(dmu, d.N, d.L, 1, c.G(P_FC_MU_B), c.s));
-    TRY(chan_sum(dlv, d.N, d.L, 1, c.G(P_FC_LV_B), c.s));
+    TRY(chan_sum(dmu, d.N, d.L, 1, c.G(P_FC_MU_B), c.part(), c.s));
+    TRY(chan_sum(dlv, d.N, d.L, 1, c.G(P_FC_LV_B), c.part(), c.s));
     const float* flat = c.F(w.ob[3]);
     TRY(run(c, LIN_WGRAD, dmu, flat, nullptr, c.G(P_FC_MU_W), 1, d.F, d.L, 1));
     TRY(run(c, LIN_WGRAD, dlv, flat, nullptr, c.G(P_FC_LV_W), 1, d.F, d.L, 1));
@@ -196,13 +205,13 @@ int backward_block(const C32& c, int b, const void* const* masks) {
     const DropCfg drop = make_drop(c.cfg->p_dropout, masks ? masks[b] : nullptr, c.cfg->seed, c.cfg->step, VAE_STREAM_DROPOUT0 + b,
                                    c.cfg->rank);
     TRY(bn_act_bwd(ga, c.F(w.yb[b]), c.coef(2 * b + 1), 256, c.P(8 * b + 6), b < 3 ? (const unsigned char*)(c.w + w.arg[b]) : nullptr,
-                   gb, c.G(8 * b + 6), c.G(8 * b + 7), sums, d.N, C, H, H, b < 3, drop, c.s));
-    TRY(chan_sum(gb, d.N, C, H * H, c.G(8 * b + 5), c.s));
+                   gb, c.G(8 * b + 6), c.G(8 * b + 7), sums, c.part(), d.N, C, H, H, b < 3, drop, c.s));
+    TRY(chan_sum(gb, d.N, C, H * H, c.G(8 * b + 5), c.part(), c.s));
     TRY(run(c, CONV_WGRAD, gb, c.F(w.aa[b]), nullptr, c.G(8 * b + 4), H, C, C, 3));
     TRY(run(c, CONV_DGRAD, gb, c.P(8 * b + 4), nullptr, ga, H, C, C, 3));
-    TRY(bn_act_bwd(ga, c.F(w.ya[b]), c.coef(2 * b), 256, c.P(8 * b + 2), nullptr, gb, c.G(8 * b + 2), c.G(8 * b + 3), sums, d.N, C, H,
+    TRY(bn_act_bwd(ga, c.F(w.ya[b]), c.coef(2 * b), 256, c.P(8 * b + 2), nullptr, gb, c.G(8 * b + 2), c.G(8 * b + 3), sums, c.part(), d.N, C, H,
                    H, 0, no_drop(), c.s));
-    TRY(chan_sum(gb, d.N, C, H * H, c.G(8 * b + 1), c.s));
+    TRY(chan_sum(gb, d.N, C, H * H, c.G(8 * b + 1), c.part(), c.s));
     const int Ci = b ? ENC_C[b - 1] : d.Cin;
     const float* xin = b ? c.F(w.ob[b - 1]) : c.F(w.x);
     TRY(run(c, CONV_WGRAD, gb, xin, nullptr, c.G(8 * b), H, Ci, C, 3));

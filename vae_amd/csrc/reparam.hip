@@ -84,20 +84,27 @@ __global__ __launch_bounds__(256) void reparam_kl_fwd_kernel(
             }
         }
         if (eps_in) {
+            if (full) {
+                const float4 e4 = *(const float4*)(eps_in + i0);
+                e[0] = e4.x; e[1] = e4.y; e[2] = e4.z; e[3] = e4.w;
+            } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) e[j] = i0 + j < n ? eps_in[i0 + j] : 0.f;
+                for (int j = 0; j < 4; ++j) e[j] = i0 + j < n ? eps_in[i0 + j] : 0.f;
+            }
         } else {
             philox_normal4(key, (uint32_t)b, e);
         }
+        // one exponential per element: exp(lv) = sd * sd (two roundings instead of one, ~1e-7 relative); the
+        // accurate expf is ~12 vector instructions and this kernel is ALU-bound beside the Philox stream
+        float t[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            // one exponential per element: exp(lv) = sd * sd (two roundings instead of one, ~1e-7 relative); the
-            // accurate expf is ~12 vector instructions and this kernel is ALU-bound beside the Philox stream
             const float sd = expf(0.5f * lv[j]);
             z[j] = m[j] + sd * e[j];
-            if (i0 + j < n) acc += 1.f + lv[j] - m[j] * m[j] - sd * sd;
+            t[j] = 1.f + lv[j] - m[j] * m[j] - sd * sd;
         }
-        if (full) {
+        if (full) {            // whole block: no per-element bounds checks (same order of the four additions as below)
+            acc += t[0]; acc += t[1]; acc += t[2]; acc += t[3];
             if (z_f32) *(float4*)(z_f32 + i0) = make_float4(z[0], z[1], z[2], z[3]);
             if (z_bf16) *(uint2*)(z_bf16 + i0) = make_uint2(pack2bf(z[0], z[1]), pack2bf(z[2], z[3]));
             if (eps_out) *(float4*)(eps_out + i0) = make_float4(e[0], e[1], e[2], e[3]);
@@ -105,6 +112,7 @@ __global__ __launch_bounds__(256) void reparam_kl_fwd_kernel(
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 if (i0 + j < n) {
+                    acc += t[j];
                     if (z_f32) z_f32[i0 + j] = z[j];
                     if (z_bf16) z_bf16[i0 + j] = f2bf(z[j]);
                     if (eps_out) eps_out[i0 + j] = e[j];
