@@ -12,7 +12,7 @@ subtraction magnifies that.  The numbers below are therefore the floor for compa
 Also recorded: the distance of the bf16 oracle from the fp32 oracle, and the same with the stored pre-BatchNorm tensor
 re-centred per channel before rounding (the best a shift of the stored tensor could do).
 
-    python tools_bf16_noise_floor.py  ->  profiles/r02_bf16_noise_floor.json
+    python tools_bf16_noise_floor.py [out.json]  (the result is committed under profiles/)
 """
 import json
 import os
@@ -98,7 +98,7 @@ def main():
     for name in ("a32_train", "b64_train"):
         rep[name] = {"same_function_other_summation_order": reorder_experiment(name), "stored_tensor_recentred": shift_experiment(name)}
         print(name, json.dumps(rep[name]))
-    path = os.path.join(ROOT, "profiles", "r02_bf16_noise_floor.json")
+    path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "bf16_noise_floor.json")
     with open(path, "w") as f:
         json.dump(rep, f, indent=1)
     print("wrote", path)

@@ -1,6 +1,6 @@
 """fp32 mode: distance of the GPU path and of the fp32 CPU oracle from the fp64 evaluation of the same function
 (forward outputs and every gradient tensor), for the reference's batch-64 configuration and a batch of 512.
-Writes profiles/r02_parity_fp32.json.  Run on the GPU box: python tools_parity_fp32.py"""
+Run on the GPU box: python tools_parity_fp32.py [out.json]; the result is committed under profiles/."""
 import json
 import os
 import sys
@@ -59,7 +59,9 @@ if __name__ == "__main__":
                    "this fp32 evaluation rounded the other way",
            "cases": [case(64, 0.0, 11), case(64, 0.1, 11), case(512, 0.1, 5)]}
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
-    with open(os.path.join(ROOT, "profiles", "r02_parity_fp32.json"), "w") as f:
+    path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "parity_fp32.json")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "w") as f:
         json.dump(res, f, indent=1)
     for c in res["cases"]:
         print(c["batch"], c["p_dropout"], c["recon"], c["mu"], c["grad_tensors_gpu_within_2e-5_of_fp64"],

@@ -91,7 +91,7 @@ def main():
         x = torch.rand(N, 3, S, S, generator=torch.Generator().manual_seed(7))
         eps, masks = philox_inputs(N, L, S, 0.1, 1337, 5)
         report[tag] = run_case(tag, m, sd, x, eps, masks, 0.1, 4.0 if L == 512 else 1.0)
-    path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r02_parity.json")
+    path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "parity.json")
     os.makedirs(os.path.dirname(path), exist_ok=True)
     with open(path, "w") as f:
         json.dump(report, f, indent=1)

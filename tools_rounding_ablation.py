@@ -2,7 +2,7 @@
 bf16 path's rounding points (weights, stored pre-BatchNorm tensors, stored activations, stored gradients) switched on
 alone and together, and with the pre-BatchNorm tensors stored as deviations from a per-channel constant
 ("shift").  CPU only (test infrastructure: imports the oracle).  python tools_rounding_ablation.py [batch]
--> profiles/r02_rounding_ablation.json"""
+-> the JSON file named on the command line (committed under profiles/)"""
 import sys, math, json
 import os
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -80,4 +80,4 @@ for name, kw in [("all", dict(rw=1,ry=1,ra=1,rg=1)), ("all_shift", dict(rw=1,ry=
 os.makedirs(os.path.join(ROOT, 'profiles'), exist_ok=True)
 json.dump({"note": "relative L2 against the fp32 oracle, batch %d, 32x32, latent 128; rw / ry / ra / rg = bf16 rounding of weights / "
                    "stored pre-BatchNorm tensors / stored activations / stored gradients" % B, "variants": out},
-          open(os.path.join(ROOT, 'profiles', 'r02_rounding_ablation.json'), 'w'), indent=1)
+          open(sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, 'gpurun_out', 'rounding_ablation.json'), 'w'), indent=1)
