@@ -71,3 +71,60 @@ def test_image_grid_layout(tmp_path):
     assert (arr[6:10, 8:14] == [0, 255, 0]).all()                  # image 4 (row 1, column 1) is green
     assert (arr[6:10, 15:21] == 0).all()                           # the empty cell stays black
     data.save_image_grid(imgs[:, :1], str(tmp_path / "grey.png"))  # one channel, through PIL
+
+
+# ---------------------------------------------------------------------- CIFAR-10 batch files (train.py:266-274)
+def _write_cifar_like(root, n_per_file=7, seed=0):
+    """files in the layout of the CIFAR-10 python version, written the way the originals were: a pickled dict with a
+    uint8 [n, 3072] array of CHW planes and a list of labels"""
+    import os
+    import pickle
+    import numpy as np
+    base = os.path.join(root, "cifar-10-batches-py")
+    os.makedirs(base)
+    rng = np.random.default_rng(seed)
+    all_data, all_labels = {}, {}
+    for name in [f"data_batch_{i}" for i in range(1, 6)] + ["test_batch"]:
+        data = rng.integers(0, 256, size=(n_per_file, 3072), dtype=np.uint8)
+        labels = [int(v) for v in rng.integers(0, 10, size=n_per_file)]
+        with open(os.path.join(base, name), "wb") as f:
+            pickle.dump({"batch_label": name, "labels": labels, "data": data, "filenames": [f"{name}_{i}.png" for i in range(n_per_file)]},
+                        f, protocol=2)
+        all_data[name], all_labels[name] = data, labels
+    return all_data, all_labels
+
+
+def test_load_cifar10_reads_the_batch_files_in_dataset_order(tmp_path):
+    import numpy as np
+    from vae_amd.data import load_cifar10
+    data, labels = _write_cifar_like(str(tmp_path))
+    images, lab = load_cifar10(str(tmp_path), train=True)
+    assert images.shape == (35, 32, 32, 3) and images.dtype == np.uint8 and lab.shape == (35,) and lab.dtype == np.int64
+    want = np.concatenate([data[f"data_batch_{i}"] for i in range(1, 6)]).reshape(-1, 3, 32, 32).transpose(0, 2, 3, 1)
+    assert np.array_equal(images, want)                       # CHW planes -> HWC pixels, files in order
+    assert lab.tolist() == sum((labels[f"data_batch_{i}"] for i in range(1, 6)), [])
+    test_images, test_lab = load_cifar10(str(tmp_path), train=False)
+    assert np.array_equal(test_images, data["test_batch"].reshape(-1, 3, 32, 32).transpose(0, 2, 3, 1))
+    assert test_lab.tolist() == labels["test_batch"]
+
+
+def test_load_cifar10_executes_nothing_from_the_file(tmp_path):
+    """a pickle that names any other global (here: os.system) is refused before anything is called"""
+    import os
+    import pickle
+    import pytest
+    from vae_amd.data import load_cifar10
+    _write_cifar_like(str(tmp_path))
+    marker = os.path.join(str(tmp_path), "executed")
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, (f"touch {marker}",))
+
+    with open(os.path.join(str(tmp_path), "cifar-10-batches-py", "data_batch_3"), "wb") as f:
+        pickle.dump({"data": Evil(), "labels": []}, f, protocol=2)
+    with pytest.raises(pickle.UnpicklingError, match="refusing to load global"):
+        load_cifar10(str(tmp_path), train=True)
+    assert not os.path.exists(marker)
+    with pytest.raises(FileNotFoundError):
+        load_cifar10(os.path.join(str(tmp_path), "nowhere"))

@@ -11,6 +11,10 @@
   (show_reconstructions, show_samples, interpolate_latents) without matplotlib: they return tensors and write a
   PPM/PNG grid.  ``python -m vae_amd`` runs them from a checkpoint (vae_amd/__main__.py).
 
+* ``load_cifar10`` reads the ``cifar-10-batches-py`` files that ``datasets.CIFAR10(root, train=True)`` of
+  train.py:266-274 reads, into the uint8 HWC array ``DeviceFeed`` takes -- through an unpickler that can build
+  nothing but dicts, lists, strings and numpy arrays.
+
 There is no CPU path here either: ``DeviceFeed`` calls the HIP library and fails if it is absent.
 """
 from __future__ import annotations
@@ -22,6 +26,57 @@ import numpy as np
 import torch
 
 from . import _lib
+
+
+# ---------------------------------------------------------------------- CIFAR-10 batch files
+class _ArrayOnlyUnpickler(__import__("pickle").Unpickler):
+    """The CIFAR-10 "python version" batch files are pickles of a dict {b'data': uint8 [10000, 3072], b'labels': list,
+    b'batch_label', b'filenames'}.  A pickle can name any importable callable; this unpickler resolves only the three
+    globals a numpy array needs plus the bytes constructor of protocol-2 pickles (and refuses everything else), so loading a file can execute nothing."""
+    # (_codecs.encode: how Python 3 writes a bytes object into a protocol-2 pickle; it turns a str into bytes)
+    _ALLOWED = {("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+                ("numpy", "ndarray"), ("numpy", "dtype"), ("_codecs", "encode")}
+
+    def find_class(self, module, name):
+        if (module, name) not in self._ALLOWED:
+            import pickle
+            raise pickle.UnpicklingError(f"refusing to load global {module}.{name}: a CIFAR-10 batch file holds only "
+                                         "dicts, lists, byte strings and numpy arrays")
+        if module == "_codecs":
+            import _codecs
+            return _codecs.encode
+        if name == "_reconstruct":
+            try:
+                from numpy._core.multiarray import _reconstruct      # numpy >= 2
+            except ImportError:
+                from numpy.core.multiarray import _reconstruct
+            return _reconstruct
+        return getattr(np, name)
+
+
+def load_cifar10(root: str, train: bool = True) -> Tuple[np.ndarray, np.ndarray]:
+    """(images uint8 [N, 32, 32, 3], labels int64 [N]) from ``root/cifar-10-batches-py`` -- ``data_batch_1..5`` for
+    ``train=True`` (N = 50000), ``test_batch`` otherwise -- in file order, which is the sample order of torchvision's
+    ``CIFAR10`` dataset (train.py:266-274 builds it with ``download=False``; the stored rows are CHW planes and are
+    turned into HWC here, as torchvision does before ``ToTensor``).  Feed the images to ``DeviceFeed``."""
+    base = os.path.join(root, "cifar-10-batches-py")
+    names = [f"data_batch_{i}" for i in range(1, 6)] if train else ["test_batch"]
+    images, labels = [], []
+    for name in names:
+        path = os.path.join(base, name)
+        if not os.path.isfile(path):
+            raise FileNotFoundError(f"{path} not found (download_data is not supported: place the extracted "
+                                    "cifar-10-batches-py directory under data_root)")
+        with open(path, "rb") as f:
+            entry = _ArrayOnlyUnpickler(f, encoding="latin1").load()
+        data = entry["data"] if "data" in entry else entry[b"data"]
+        lab = entry.get("labels", entry.get(b"labels", entry.get("fine_labels")))
+        data = np.asarray(data)
+        if data.dtype != np.uint8 or data.ndim != 2 or data.shape[1] != 3072 or lab is None or len(lab) != data.shape[0]:
+            raise ValueError(f"{path}: not a CIFAR-10 batch (data {data.dtype} {data.shape})")
+        images.append(data.reshape(-1, 3, 32, 32).transpose(0, 2, 3, 1))
+        labels.append(np.asarray(lab, dtype=np.int64))
+    return np.ascontiguousarray(np.concatenate(images)), np.concatenate(labels)
 
 
 def split_indices(n: int, p_train_len: float, generator: Optional[torch.Generator] = None) -> Tuple[torch.Tensor, torch.Tensor]:
