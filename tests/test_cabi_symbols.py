@@ -55,8 +55,37 @@ def test_no_torch_types_in_header():
 
 def test_version_and_error_string():
     lib = L.load()
-    assert lib.vae_version() >= 1
+    assert lib.vae_version() == L.ABI_VERSION
     assert isinstance(lib.vae_last_error(), bytes)
+    # the header's revision is the one the binding was written for
+    with open(os.path.join(ROOT, "include", "vae_hip.h")) as f:
+        assert f"#define VAE_HIP_VERSION {L.ABI_VERSION}\n" in f.read()
+
+
+def test_binding_refuses_a_library_of_another_abi_revision(monkeypatch):
+    """a caller built against an older header must not reach the kernels with a shorter struct"""
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "ABI_VERSION", L.ABI_VERSION + 1)
+    with pytest.raises(RuntimeError, match="ABI revision"):
+        L.load()
+
+
+def test_model_cfg_of_another_size_is_rejected():
+    lib = L.load()
+    cfg = _cfg(8, 128, 32)
+    assert cfg.struct_size == ctypes.sizeof(L.ModelCfg) and lib.vae_model_param_count(ctypes.byref(cfg)) > 0
+    cfg.struct_size -= 16           # what a binding built before the last two fields were added would pass
+    assert lib.vae_model_param_count(ctypes.byref(cfg)) == -1
+    assert lib.vae_model_workspace_bytes(ctypes.byref(cfg)) == -1
+    assert b"struct_size" in lib.vae_last_error()
+
+
+def test_tuning_keys_are_range_checked():
+    L.call("vae_set_tuning", b"conv3_wide", 0)
+    with pytest.raises(RuntimeError, match="out of range"):
+        L.call("vae_set_tuning", b"conv3_wide", 7)
+    with pytest.raises(RuntimeError, match="unknown key"):
+        L.call("vae_set_tuning", b"conv3_cu_budget", 1)
 
 
 def test_missing_library_fails_loudly(monkeypatch):
