@@ -372,7 +372,10 @@ int gemm(int mode, const Gemm& q, hipStream_t s) {
     VAE_CHECK(grid.y < 65536 && grid.z < 65536, "f32 gemm: grid too large");
     const dim3 fgrid((unsigned)((M * N + 255) / 256));
     {
-        ProfScope prof("gemm_f32_kernel", 2.0 * (double)M * (double)N * (double)K, 0.0, s);
+        static const char* const names[9] = {"gemm_f32_kernel<conv fwd>", "gemm_f32_kernel<conv dgrad>", "gemm_f32_kernel<conv wgrad>",
+                                             "gemm_f32_kernel<convT fwd>", "gemm_f32_kernel<convT dgrad>", "gemm_f32_kernel<convT wgrad>",
+                                             "gemm_f32_kernel<linear fwd>", "gemm_f32_kernel<linear dgrad>", "gemm_f32_kernel<linear wgrad>"};
+        ProfScope prof(names[mode], 2.0 * (double)M * (double)N * (double)K, 0.0, s);
 #define GO(MD, KS_)                                                                         \
         do {                                                                                \
             hipLaunchKernelGGL((gemm_f32_kernel<MD, KS_>), grid, dim3(256), 0, s, g);       \
