@@ -32,6 +32,10 @@ __device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)"
 // 128 B with the chunk index XOR-swizzled by the row, the layout of the conv kernels' weight tiles) right before its
 // use: reads, wait, matrix instructions -- the order hipcc gives the conv kernels' K loop.  MODE 2: the same reads
 // software-pipelined by hand: the fragments of the next k-half are requested before this half's matrix instructions.
+// MODE 3: MODE 1 plus a workgroup barrier in front of every K-step (two k-halves), as the conv kernels have for their
+// weight ring.  MODE 4: MODE 3 with the first k-half's four ACTIVATION fragments of the next K-step requested before
+// that barrier (the patch does not change between taps; only the weight fragments must wait for the barrier).
+// MODE 5: MODE 4 plus the second k-half's fragments requested before the first half's matrix instructions.
 // SHAPE 0: 16x16x32 (4 x 4 accumulators of 4 registers), 1: 32x32x16 (2 x 2 accumulators of 16 registers)
 template <int MODE, int SHAPE>
 __global__ __launch_bounds__(512) void loop_kernel(const uint4* __restrict__ src, float* __restrict__ sink, Stamp* __restrict__ stamps,
@@ -94,8 +98,33 @@ __global__ __launch_bounds__(512) void loop_kernel(const uint4* __restrict__ src
     };
     const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     if (MODE == 2) { fetch(0); }
+    auto fetch_a = [&](int ks) {
+#pragma unroll
+        for (int i = 0; i < NF; ++i) a[ks][i] = lds_read128(base + (a_addr[i] ^ (ks * 64)));
+    };
+    auto fetch_b = [&](int ks) {
+#pragma unroll
+        for (int i = 0; i < NF; ++i) b[ks][i] = lds_read128(base + (b_addr[i] ^ (ks * 64)));
+    };
+    if (MODE >= 4) fetch_a(0);
     for (int it = 0; it < iters; ++it) {
         // one "K-step" of the conv kernels: 64 channels = two k-halves
+        if (MODE >= 3) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (MODE == 3) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) { fetch(ks); lds_wait(); mfmas(ks); }
+        } else if (MODE == 4) {
+            fetch_b(0); lds_wait(); mfmas(0);
+            fetch(1); lds_wait(); mfmas(1);
+            fetch_a(0);                              // the next K-step's activation fragments, ahead of its barrier
+        } else if (MODE == 5) {
+            fetch_b(0); lds_wait();
+            fetch(1); __builtin_amdgcn_sched_barrier(0);
+            mfmas(0); __builtin_amdgcn_sched_barrier(0);
+            lds_wait();
+            fetch_a(0); __builtin_amdgcn_sched_barrier(0);
+            mfmas(1); __builtin_amdgcn_sched_barrier(0);
+        } else {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             if (MODE == 1) { fetch(ks); lds_wait(); }
@@ -106,6 +135,7 @@ __global__ __launch_bounds__(512) void loop_kernel(const uint4* __restrict__ src
             }
             mfmas(ks);
             if (MODE == 2) __builtin_amdgcn_sched_barrier(0);
+        }
         }
     }
     const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -183,6 +213,9 @@ int main() {
     run<1, 0>("8 ds_read_b128, wait, 16 mfma, 16x16x32", 2, src, sink, stamps, false);
     run<2, 0>("8 ds_read_b128 one half ahead of 16 mfma, 16x16x32", 1, src, sink, stamps, false);
     run<2, 0>("8 ds_read_b128 one half ahead of 16 mfma, 16x16x32", 2, src, sink, stamps, false);
+    run<3, 0>("barrier per K-step, then 8 reads, wait, 16 mfma per half, 16x16x32", 2, src, sink, stamps, false);
+    run<4, 0>("the same, the next K-step's 4 activation fragments requested before its barrier", 2, src, sink, stamps, false);
+    run<5, 0>("the same, and the second half's fragments before the first half's mfma", 2, src, sink, stamps, false);
     run<0, 1>("mfma only, 32x32x16", 1, src, sink, stamps, false);
     run<0, 1>("mfma only, 32x32x16", 2, src, sink, stamps, false);
     run<1, 1>("4 ds_read_b128, wait, 8 mfma, 32x32x16", 1, src, sink, stamps, false);
