@@ -70,7 +70,9 @@ int vae_prof_stop(char* names, int* launches, double* total_ms, double* flops, d
  * vae_model_backward(stage = -1) folds every split-K slab in one launch at its end (default), 1 in one launch per stage;
  * "slab_reparam" = 0 the whole-model passes let the reparameterisation kernels add up the split-K slabs of the latent GEMMs
  * (default), 1 a finishing kernel does; "convt_bwd" = 0 the 64 -> 64 ConvTranspose backward as one kernel that also makes the head's gradient
- * on the way (default), 1 as separate input- and weight-gradient kernels, 2 one kernel reading the stored gradient.  Unknown keys and
+ * on the way (default), 1 as separate input- and weight-gradient kernels, 2 one kernel reading the stored gradient; "wgrad_batch" = 0
+ * vae_model_backward computes the conv3x3 weight gradients of a backward stage in ONE launch (vae_conv3_wgrad_patch_multi: a seventh
+ * of the split-K slab traffic; default), 1 one launch per layer.  Unknown keys and
  * values outside a key's range are rejected.  Not thread-safe: set it while nothing is being launched, and never
  * between a vae_model_forward and its vae_model_backward: some keys change the workspace carving that
  * vae_model_workspace_bytes and both passes derive from the config. */
@@ -227,6 +229,21 @@ int vae_conv3_wgrad_patch_ok(int H, int W, int Cin, int Cout);
 int vae_conv3_wgrad_patch_ksplit(int n_img, int H, int W, int Cin, int Cout);
 int vae_conv3_wgrad_patch(const void* dy, const void* x, float* slab, int n_img, int H, int W,
                           int Cin, int Cout, int nsplit, void* stream);
+/* The same for several conv layers in ONE launch (the Conv2d weight gradients of a backward stage, vae/models/vae.py:129,133
+ * x 2-4 layers): the launch's workgroups are dealt out over the jobs in proportion to their work.  A launch that fills
+ * the chip writes one 147 KB slab per CU whatever it computes, so batching divides the split-K slab traffic by the
+ * number of jobs.  vae_conv3_wgrad_multi_plan fills nsplit_out[i] so that the launch has at most max_wgs workgroups
+ * (<= 0: 256, one per CU) with about equal K ranges; job i needs nsplit[i] * 9 * Cout * Cin floats of slab, laid out as
+ * vae_conv3_wgrad_patch lays it out.  Every job's geometry must pass vae_conv3_wgrad_patch_ok. */
+#define VAE_MAX_WGRAD_JOBS 8
+typedef struct vae_wgrad_job {
+    const void* dy;     /* [n_img*H*W][Cout] bf16 */
+    const void* x;      /* [n_img*H*W][Cin]  bf16 */
+    float* slab;
+    int n_img, H, W, Cin, Cout, nsplit;
+} vae_wgrad_job;
+int vae_conv3_wgrad_multi_plan(const vae_wgrad_job* jobs, int njobs, int max_wgs, int* nsplit_out);
+int vae_conv3_wgrad_patch_multi(const vae_wgrad_job* jobs, int njobs, void* stream);
 /* out[e] (+)= sum_s slab[s*slab_stride + base + i0*s0+i1*s1+i2*s2+i3*s3] where e is the row-major
  * index over dims4 = (D0,D1,D2,D3): folds the K splits and converts the kernels' packed
  * layout to the parameter's own layout (e.g. Conv2d [Cout][Cin][3][3]). */

@@ -178,3 +178,31 @@ def test_geometry_helpers():
         s = L.call("vae_conv3_wgrad_patch_ksplit", n, H, H, Ci, Co)
         assert 1 <= s <= (n * H * H + 63) // 64
     assert L.call("vae_recon_loss_grid", 1) >= 1 and L.call("vae_reparam_grid", 1) >= 1 and L.call("vae_adamw_grid", 1) >= 1
+
+
+@pytest.mark.parametrize("n,size,max_wgs", [(512, 32, 256), (512, 64, 256), (4, 32, 256), (1, 32, 256), (64, 32, 16)])
+def test_batched_weight_gradient_plan(n, size, max_wgs):
+    """the K splits one launch over several conv3x3 weight gradients is planned with: every layer gets at least one
+    workgroup per output tile, the launch stays within the workgroup budget whenever the tiles alone fit in it, no split
+    is empty, and K tiles per workgroup are even across layers (within a factor of two of each other where a layer
+    has enough of them to split)"""
+    geo = [(size // 8, 256, 256), (size // 8, 128, 256), (size // 4, 128, 128), (size // 4, 64, 128), (size // 2, 64, 64)]
+    jobs = (L.WgradJob * len(geo))()
+    for q, (H, Ci, Co) in zip(jobs, geo):
+        q.n_img, q.H, q.W, q.Cin, q.Cout = n, H, H, Ci, Co
+    ns = (ctypes.c_int * len(geo))()
+    L.call("vae_conv3_wgrad_multi_plan", jobs, len(geo), max_wgs, ns)
+    tiles = [(Ci // 64) * (Co // 64) for _, Ci, Co in geo]
+    ktiles = [-(-n * H * H // 64) for H, _, _ in geo]
+    assert all(1 <= s <= k for s, k in zip(ns, ktiles))
+    assert sum(t * s for t, s in zip(tiles, ns)) <= max(max_wgs, sum(tiles))
+    per = [-(-k // s) for k, s in zip(ktiles, ns)]
+    assert all((s - 1) * p < k for s, p, k in zip(ns, per, ktiles))          # no empty split
+    split = [p for p, s in zip(per, ns) if s > 1]
+    if split:
+        assert max(split) <= 2 * min(split)
+    jobs[0].H = 6
+    with pytest.raises(RuntimeError, match="not covered"):
+        L.call("vae_conv3_wgrad_multi_plan", jobs, len(geo), max_wgs, ns)
+    with pytest.raises(RuntimeError, match="out of range"):
+        L.call("vae_conv3_wgrad_multi_plan", jobs, 9, max_wgs, ns)

@@ -142,6 +142,69 @@ def _check_conv3x3_wgrad_patch(L, n, H, W, Ci, Co, ns):
     assert rel_l2(dw.cpu(), w.grad) <= 1e-4
 
 
+def _stage_jobs(n, size):
+    """(H, Ci, Co) of the conv3x3 layers VAEConv's backward hands to one launch: blocks 3 + 2, then blocks 1 + 0."""
+    return ([(size // 8, 256, 256), (size // 8, 128, 256), (size // 4, 128, 128), (size // 4, 64, 128)],
+            [(size // 2, 64, 64), (size // 2, 64, 64), (size, 64, 64)])
+
+
+@pytest.mark.parametrize("n,size,max_wgs", [(16, 32, 256), (3, 32, 256), (8, 64, 256), (64, 32, 64), (5, 32, 8)])
+def test_conv3x3_wgrad_patch_multi(L, n, size, max_wgs):
+    """several layers' weight gradients from ONE launch (each workgroup finds its layer by its index) == the per-layer
+    launch on the same operands with the same K split, bit for bit, and == autograd's gradient; layers of different
+    widths share the launch, at budgets above and below the number of output tiles"""
+    import ctypes
+    g = torch.Generator().manual_seed(n + size)
+    for geo in _stage_jobs(n, size):
+        jobs = (L.WgradJob * len(geo))()
+        keep, want = [], []
+        for q, (H, Ci, Co) in zip(jobs, geo):
+            x = bf(torch.randn(n, Ci, H, H, generator=g))
+            dy = bf(torch.randn(n, Co, H, H, generator=g))
+            w = torch.zeros(Co, Ci, 3, 3, requires_grad=True)
+            F.conv2d(x, w, None, padding=1).backward(dy)
+            xd, dyd = nhwc(x), nhwc(dy)
+            keep.append((xd, dyd))
+            want.append(w.grad)
+            q.dy, q.x, q.n_img, q.H, q.W, q.Cin, q.Cout = L.ptr(dyd), L.ptr(xd), n, H, H, Ci, Co
+        ns = (ctypes.c_int * len(geo))()
+        L.call("vae_conv3_wgrad_multi_plan", jobs, len(geo), max_wgs, ns)
+        tiles = [(Ci // 64) * (Co // 64) for _, Ci, Co in geo]
+        assert sum(t * s for t, s in zip(tiles, ns)) <= max(max_wgs, sum(tiles))
+        slabs = []
+        for q, s, (H, Ci, Co) in zip(jobs, ns, geo):
+            assert 1 <= s <= (n * H * H + 63) // 64
+            slabs.append(torch.full((s, Co, 9, Ci), float("nan"), device=DEV))
+            q.slab, q.nsplit = L.ptr(slabs[-1]), s
+        L.call("vae_conv3_wgrad_patch_multi", jobs, len(geo), L.current_stream())
+        for slab, s, (xd, dyd), ref, (H, Ci, Co) in zip(slabs, ns, keep, want, geo):
+            dw = slab.sum(0).permute(0, 2, 1).reshape(Co, Ci, 3, 3)
+            assert rel_l2(dw.cpu(), ref) <= 1e-4, (H, Ci, Co)
+            one = torch.full((s, Co, 9, Ci), float("nan"), device=DEV)
+            L.call("vae_set_tuning", b"wgrad_pc", 1)          # the form of the kernel the shared launch is built from
+            try:
+                L.call("vae_conv3_wgrad_patch", L.ptr(dyd), L.ptr(xd), L.ptr(one), n, H, H, Ci, Co, s, L.current_stream())
+            finally:
+                L.call("vae_set_tuning", b"wgrad_pc", 0)
+            assert torch.equal(one, slab), (H, Ci, Co)
+
+
+def test_conv3x3_wgrad_patch_multi_rejects(L):
+    jobs = (L.WgradJob * 1)()
+    t = torch.zeros(64, device=DEV)
+    q = jobs[0]
+    q.dy = q.x = q.slab = L.ptr(t)
+    q.n_img, q.H, q.W, q.Cin, q.Cout, q.nsplit = 1, 6, 6, 64, 64, 1
+    with pytest.raises(RuntimeError, match="not covered"):
+        L.call("vae_conv3_wgrad_patch_multi", jobs, 1, L.current_stream())
+    with pytest.raises(RuntimeError, match="out of range"):
+        L.call("vae_conv3_wgrad_patch_multi", jobs, 0, L.current_stream())
+    q.H = q.W = 8
+    q.nsplit = 5                  # more splits than the single K tile of one 8x8 image
+    with pytest.raises(RuntimeError):
+        L.call("vae_conv3_wgrad_patch_multi", jobs, 1, L.current_stream())
+
+
 def test_conv3x3_wgrad_patch_rejects(L):
     assert L.call("vae_conv3_wgrad_patch_ok", 6, 6, 64, 64) == 0
     assert L.call("vae_conv3_wgrad_patch_ok", 8, 8, 32, 64) == 0

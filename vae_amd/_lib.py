@@ -58,6 +58,8 @@ SIGNATURES = {
     "vae_conv3_wgrad_patch_ok": (c_int, [c_int, c_int, c_int, c_int]),
     "vae_conv3_wgrad_patch_ksplit": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "vae_conv3_wgrad_patch": (None, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "vae_conv3_wgrad_multi_plan": (None, [P, c_int, c_int, P]),
+    "vae_conv3_wgrad_patch_multi": (None, [P, c_int, P]),
     "vae_reduce_slabs": (None, [P, c_int, c_long, P, P, P, c_long, c_int, P]),
     "vae_pack_bf16": (None, [P, P, P, P, c_long, P]),
     "vae_bn_finalize": (None, [P, P, c_int, c_int, c_int, c_double, P, P, P, P, c_float, c_float, c_int,
@@ -134,6 +136,12 @@ class ModelCfg(ctypes.Structure):
     def __init__(self, *args, **kw):
         super().__init__(*args, **kw)
         self.struct_size = ctypes.sizeof(ModelCfg)      # the library compares it with its own sizeof(vae_model_cfg)
+
+
+class WgradJob(ctypes.Structure):
+    """mirror of struct vae_wgrad_job (include/vae_hip.h)."""
+    _fields_ = [("dy", c_void_p), ("x", c_void_p), ("slab", c_void_p), ("n_img", c_int), ("H", c_int), ("W", c_int),
+                ("Cin", c_int), ("Cout", c_int), ("nsplit", c_int)]
 
 
 ABI_VERSION = 3                          # VAE_HIP_VERSION of the include/vae_hip.h these signatures were written for

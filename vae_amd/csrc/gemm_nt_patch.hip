@@ -328,19 +328,19 @@ __global__ __launch_bounds__(512, 1) void conv3_wgrad_patch_kernel(const PatchP 
 // copy issue (0.9 us per round), the fragment reads and the MFMAs (0.55 us) simply add up.  Here waves 4-7 only copy
 // and waves 0-3 only compute, two 64-pixel K tiles per barrier out of two pairs of stages: ONE accumulator set per
 // workgroup (no hand-over between groups), and the copies of round q + 1 run under the matrix instructions of round q.
+constexpr int PC_STAGE = 64 * ROWB + PATCH_ROWS_MAX * ROWB, PC_SMEM_BYTES = 4 * PC_STAGE;
+static_assert(PC_SMEM_BYTES <= 160 * 1024 && 4 * 64 * 16 * 16 <= PC_SMEM_BYTES, "LDS");
+
+// the workgroup's job: weight block (ci from n0, co from m0) of problem p, K tiles [split * kps, + kps)
 template <int W>
-__global__ __launch_bounds__(512, 1) void conv3_wgrad_pc_kernel(const PatchP p) {
+__device__ __forceinline__ void wgrad_pc_body(const PatchP& p, int n0, int m0, int split, unsigned char* smem) {
     constexpr int W2 = W + 2;
     constexpr int QD = 2;     // input fragments requested ahead (4 measured: 10 % slower)
-    constexpr int P_BYTES = 64 * ROWB, Q_BYTES = PATCH_ROWS_MAX * ROWB, STAGE = P_BYTES + Q_BYTES;
-    constexpr int SMEM_BYTES = 4 * STAGE;
+    constexpr int P_BYTES = 64 * ROWB, STAGE = PC_STAGE;
     constexpr int QI = PATCH_INSTR_PER_WAVE;
-    static_assert(SMEM_BYTES <= 160 * 1024 && 4 * 64 * 16 * 16 <= SMEM_BYTES, "LDS");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int role = __builtin_amdgcn_readfirstlane(tid >> 8), wave = __builtin_amdgcn_readfirstlane((tid >> 6) & 3);   // 0: compute, 1: copy
-    const int n0 = blockIdx.x * 64, m0 = blockIdx.y * 64, split = blockIdx.z;
     const int kt_beg = split * p.kps, kt_end = min(kt_beg + p.kps, p.ktiles);
     const int ntile = kt_end - kt_beg;
 
@@ -540,6 +540,45 @@ __global__ __launch_bounds__(512, 1) void conv3_wgrad_pc_kernel(const PatchP p) 
     }
 }
 
+template <int W>
+__global__ __launch_bounds__(512, 1) void conv3_wgrad_pc_kernel(const PatchP p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[PC_SMEM_BYTES];
+    wgrad_pc_body<W>(p, blockIdx.x * 64, blockIdx.y * 64, blockIdx.z, smem);
+}
+
+// Several weight gradients in ONE launch.  Every 512-thread workgroup of these kernels keeps a 64 x 9 x 64 fp32 accumulator
+// tile (147 KB) and leaves it as a split-K slab, so a launch that fills the 256 CUs writes 37.7 MB of slabs whatever the
+// layer is -- launched one layer at a time, the seven conv layers of the encoder wrote 264 MB of slabs per backward pass
+// for 16 MB of gradients, and the fold read them all back.  Here the workgroups of one launch are dealt out over the
+// layers in proportion to their work (a job = one layer; the planner gives every workgroup about the same number of K
+// tiles), so the LAUNCH writes 37.7 MB, each workgroup walks a K range several times as long (prologue, accumulator
+// hand-over and slab store are paid once per workgroup, not once per layer) and a backward stage has one launch
+// boundary instead of one per layer.  The price: every layer's dY must stay alive until the stage's launch.
+struct WgradJob {
+    PatchP p;
+    int W, wg0, nx, ny;       // image width (selects the instantiation), first workgroup, ci / co tiles
+};
+struct WgradJobs {
+    WgradJob j[VAE_MAX_WGRAD_JOBS];
+    int n;
+};
+__global__ __launch_bounds__(512, 1) void conv3_wgrad_multi_kernel(const WgradJobs jobs) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[PC_SMEM_BYTES];
+    int ji = 0;
+    for (int i = 1; i < jobs.n; ++i)
+        if ((int)blockIdx.x >= jobs.j[i].wg0) ji = i;       // uniform over the workgroup
+    const WgradJob& jb = jobs.j[ji];
+    const int local = (int)blockIdx.x - jb.wg0;
+    const int nxi = local % jb.nx, t = local / jb.nx, nyi = t % jb.ny, split = t / jb.ny;
+    switch (jb.W) {
+        case 4: wgrad_pc_body<4>(jb.p, nxi * 64, nyi * 64, split, smem); break;
+        case 8: wgrad_pc_body<8>(jb.p, nxi * 64, nyi * 64, split, smem); break;
+        case 16: wgrad_pc_body<16>(jb.p, nxi * 64, nyi * 64, split, smem); break;
+        case 32: wgrad_pc_body<32>(jb.p, nxi * 64, nyi * 64, split, smem); break;
+        default: wgrad_pc_body<64>(jb.p, nxi * 64, nyi * 64, split, smem); break;
+    }
+}
+
 // Which form runs (tuning key "wgrad_pc"): 0 by the K tiles per workgroup, 1 always the producer / consumer form, 2 never.
 // Measured at batch 512, 32x32 (32 K tiles per workgroup): the kernels alone 10-12 % faster (47 -> 41.5, 45 -> 39.5 us),
 // 0.258 -> 0.237 ms per step between events, but the step itself 7 us SLOWER (1.582 -> 1.589 ms, repeatedly, same box);
@@ -581,27 +620,39 @@ extern "C" int vae_conv3_wgrad_patch_ksplit(int n_img, int H, int W, int Cin, in
     return (int)((ktiles + kps - 1) / kps);
 }
 
+// geometry part of the kernel argument (everything but the K split)
+static int make_patch_p(PatchP* p, const void* dy, const void* x, float* slab, int n_img, int H, int W, int Cin, int Cout,
+                        const char* who) {
+    VAE_CHECK(dy && x && slab, "%s: null pointer", who);
+    VAE_CHECK(n_img > 0 && vae_conv3_wgrad_patch_ok(H, W, Cin, Cout),
+              "%s: geometry n=%d %dx%d Cin=%d Cout=%d not covered (use vae_wgrad_gemm)", who, n_img, H, W, Cin, Cout);
+    VAE_CHECK((long)n_img * H * W * (Cin > Cout ? Cin : Cout) * 2 < (1L << 32), "%s: operand larger than 4 GiB", who);
+    VAE_CHECK((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)slab) & 15) == 0, "%s: operands must be 16-byte aligned", who);
+    *p = PatchP{};
+    p->P = (const bf16_t*)dy; p->Q = (const bf16_t*)x; p->slab = slab;
+    p->Co = Cout; p->Ci = Cin; p->Ktot = n_img * H * W;
+    p->H = H; p->wshift = ilog2x(W);
+    const long hw = (long)H * W;
+    if (hw >= 64) { p->G = 1; p->R = 64 / W; } else { p->G = (int)(64 / hw); p->R = H; }
+    p->rwshift = ilog2x(p->R * W);
+    p->PR = p->G * (p->R + 2) * (W + 2);
+    VAE_CHECK(p->PR <= PATCH_ROWS_MAX && p->rwshift >= 0, "%s: internal geometry error", who);
+    p->ktiles = (p->Ktot + 63) / 64;
+    p->slab_stride = 9L * Cout * Cin;
+    return 0;
+}
+static int set_split(PatchP* p, int nsplit, const char* who) {
+    VAE_CHECK(nsplit >= 1 && nsplit <= p->ktiles, "%s: nsplit=%d out of range (1..%d)", who, nsplit, p->ktiles);
+    p->kps = (p->ktiles + nsplit - 1) / nsplit;
+    VAE_CHECK((long)(nsplit - 1) * p->kps < p->ktiles, "%s: nsplit=%d leaves empty splits", who, nsplit);
+    return 0;
+}
+
 extern "C" int vae_conv3_wgrad_patch(const void* dy, const void* x, float* slab, int n_img, int H, int W, int Cin,
                                      int Cout, int nsplit, void* stream) {
-    VAE_CHECK(dy && x && slab, "vae_conv3_wgrad_patch: null pointer");
-    VAE_CHECK(n_img > 0 && vae_conv3_wgrad_patch_ok(H, W, Cin, Cout),
-              "vae_conv3_wgrad_patch: geometry n=%d %dx%d Cin=%d Cout=%d not covered (use vae_wgrad_gemm)", n_img, H, W, Cin, Cout);
-    VAE_CHECK((long)n_img * H * W * (Cin > Cout ? Cin : Cout) * 2 < (1L << 32), "vae_conv3_wgrad_patch: operand larger than 4 GiB");
-    VAE_CHECK((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)slab) & 15) == 0, "vae_conv3_wgrad_patch: operands must be 16-byte aligned");
-    PatchP p = {};
-    p.P = (const bf16_t*)dy; p.Q = (const bf16_t*)x; p.slab = slab;
-    p.Co = Cout; p.Ci = Cin; p.Ktot = n_img * H * W;
-    p.H = H; p.wshift = ilog2x(W);
-    const long hw = (long)H * W;
-    if (hw >= 64) { p.G = 1; p.R = 64 / W; } else { p.G = (int)(64 / hw); p.R = H; }
-    p.rwshift = ilog2x(p.R * W);
-    p.PR = p.G * (p.R + 2) * (W + 2);
-    VAE_CHECK(p.PR <= PATCH_ROWS_MAX && p.rwshift >= 0, "vae_conv3_wgrad_patch: internal geometry error");
-    p.ktiles = (p.Ktot + 63) / 64;
-    VAE_CHECK(nsplit >= 1 && nsplit <= p.ktiles, "vae_conv3_wgrad_patch: nsplit=%d out of range (1..%d)", nsplit, p.ktiles);
-    p.kps = (p.ktiles + nsplit - 1) / nsplit;
-    VAE_CHECK((long)(nsplit - 1) * p.kps < p.ktiles, "vae_conv3_wgrad_patch: nsplit=%d leaves empty splits", nsplit);
-    p.slab_stride = 9L * Cout * Cin;
+    PatchP p;
+    if (int e = make_patch_p(&p, dy, x, slab, n_img, H, W, Cin, Cout, "vae_conv3_wgrad_patch")) return e;
+    if (int e = set_split(&p, nsplit, "vae_conv3_wgrad_patch")) return e;
     dim3 grid(Cin / 64, Cout / 64, nsplit);
     hipStream_t s = (hipStream_t)stream;
     const double flops = 2.0 * Cout * Cin * 9.0 * p.Ktot;
@@ -619,5 +670,61 @@ extern "C" int vae_conv3_wgrad_patch(const void* dy, const void* x, float* slab,
     }
 #undef GO
     VAE_LAUNCH_CHECK("conv3_wgrad_patch_kernel");
+    return 0;
+}
+
+// K splits of the jobs of one batched launch: every workgroup gets about the same number of K tiles and the launch has
+// at most `max_wgs` workgroups (one per CU: a second round of workgroups would double its time).
+extern "C" int vae_conv3_wgrad_multi_plan(const vae_wgrad_job* jobs, int njobs, int max_wgs, int* nsplit_out) {
+    VAE_CHECK(jobs && nsplit_out && njobs > 0 && njobs <= VAE_MAX_WGRAD_JOBS, "vae_conv3_wgrad_multi_plan: njobs=%d out of range (1..%d)",
+              njobs, VAE_MAX_WGRAD_JOBS);
+    if (max_wgs <= 0) max_wgs = 256;
+    long tiles[VAE_MAX_WGRAD_JOBS], ktiles[VAE_MAX_WGRAD_JOBS], total = 0, min_wgs = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const vae_wgrad_job& q = jobs[i];
+        VAE_CHECK(q.n_img > 0 && vae_conv3_wgrad_patch_ok(q.H, q.W, q.Cin, q.Cout),
+                  "vae_conv3_wgrad_multi_plan: job %d: geometry n=%d %dx%d Cin=%d Cout=%d not covered", i, q.n_img, q.H, q.W, q.Cin, q.Cout);
+        tiles[i] = (long)(q.Cin / 64) * (q.Cout / 64);
+        ktiles[i] = ((long)q.n_img * q.H * q.W + 63) / 64;
+        total += tiles[i] * ktiles[i];
+        min_wgs += tiles[i];
+    }
+    if (max_wgs < min_wgs) max_wgs = (int)min_wgs;       // more output tiles than CUs: one split each
+    long kps = (total + max_wgs - 1) / max_wgs;
+    if (kps < 8) kps = 8;                                // a split of fewer than 8 K tiles is all prologue and slab store
+    for (;; ++kps) {
+        long wgs = 0;
+        for (int i = 0; i < njobs; ++i) {
+            const long k = kps < ktiles[i] ? kps : ktiles[i];
+            const long per = (ktiles[i] + k - 1) / k;                       // splits asked for
+            const long kk = (ktiles[i] + per - 1) / per;                    // K tiles per split, evened out
+            nsplit_out[i] = (int)((ktiles[i] + kk - 1) / kk);
+            wgs += tiles[i] * nsplit_out[i];
+        }
+        if (wgs <= max_wgs) return 0;
+    }
+}
+
+extern "C" int vae_conv3_wgrad_patch_multi(const vae_wgrad_job* jobs, int njobs, void* stream) {
+    VAE_CHECK(jobs && njobs > 0 && njobs <= VAE_MAX_WGRAD_JOBS, "vae_conv3_wgrad_patch_multi: njobs=%d out of range (1..%d)", njobs,
+              VAE_MAX_WGRAD_JOBS);
+    WgradJobs wj;
+    wj.n = njobs;
+    int wgs = 0;
+    double flops = 0.0, bytes = 0.0;
+    for (int i = 0; i < njobs; ++i) {
+        const vae_wgrad_job& q = jobs[i];
+        WgradJob& d = wj.j[i];
+        if (int e = make_patch_p(&d.p, q.dy, q.x, q.slab, q.n_img, q.H, q.W, q.Cin, q.Cout, "vae_conv3_wgrad_patch_multi")) return e;
+        if (int e = set_split(&d.p, q.nsplit, "vae_conv3_wgrad_patch_multi")) return e;
+        d.W = q.W; d.wg0 = wgs; d.nx = q.Cin / 64; d.ny = q.Cout / 64;
+        wgs += d.nx * d.ny * q.nsplit;
+        flops += 2.0 * q.Cout * q.Cin * 9.0 * d.p.Ktot;
+        bytes += 2.0 * d.p.Ktot * ((double)q.Cout + q.Cin) + 4.0 * q.nsplit * 9.0 * q.Cout * q.Cin;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof("conv3_wgrad_patch_kernel", flops, bytes, s);
+    hipLaunchKernelGGL(conv3_wgrad_multi_kernel, dim3(wgs), dim3(512), 0, s, wj);
+    VAE_LAUNCH_CHECK("conv3_wgrad_multi_kernel");
     return 0;
 }

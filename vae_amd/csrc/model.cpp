@@ -15,7 +15,7 @@
 
 #include "model_layout.h"
 
-namespace vae { extern int g_conv1_bwd_mode; extern int g_pool_ymax_mode; extern int g_convt_bwd_mode; extern int g_head_sums_mode; int g_fold_defer_mode = 0; int g_slab_reparam_mode = 0; }
+namespace vae { extern int g_conv1_bwd_mode; extern int g_pool_ymax_mode; extern int g_convt_bwd_mode; extern int g_head_sums_mode; int g_fold_defer_mode = 0; int g_slab_reparam_mode = 0; int g_wgrad_batch_mode = 0; }
 
 namespace {
 using namespace vae_model;
@@ -64,6 +64,7 @@ struct WsLayout {
     long g[3];              // gradient ping-pong buffers (three: a weight-gradient kernel may still read one)
     long route[3];          // pooled blocks: one byte per pooled element, which window element won and whether it is live
     long ymax[3];           // pooled blocks: the conv output at each window's maximum (bf16), for the backward sums
+    long dyb[4], dya[4];    // gradients of the two conv outputs of each encoder block: kept until the stage's ONE weight-gradient launch
     long slab2, slab2_floats;
     long total_bytes;
 };
@@ -103,6 +104,7 @@ void make_ws_layout(const Dims& d, WsLayout* w) {
         if (u < 2) w->ad[u] = put((long)d.N * hh * hh * DEC_CO[u] * 2);
     }
     for (int i = 0; i < 3; ++i) w->g[i] = put(npix * 64 * 2);
+    for (int b = 0; b < 4; ++b) { w->dyb[b] = put(enc_elems(d, b) * 2); w->dya[b] = put(enc_elems(d, b) * 2); }
     w->bnpart = put(1024L * 512 * 4);
     w->headpart = put((long)vae_head_bwd_blocks(d.N, d.S, d.S) * (3 + d.Cout) * 64 * 4);
     w->headsums = put(7 * 64 * 4);
@@ -111,13 +113,32 @@ void make_ws_layout(const Dims& d, WsLayout* w) {
     auto up64 = [](long v) { return (v + 63) / 64 * 64; };
     long s = up64(slab_need(64, 64, 2, npix));
     if (d.Cin <= 3) { const long v = up64(vae_bn_bwd_conv1_scratch_floats(d.N, d.S, d.S)); if (v > s) s = v; }   // either form of the first conv's backward
+    // K splits of the batched weight-gradient launches (one per backward stage: convs of blocks 3 + 2, of blocks 1 + 0)
+    int batched_ns[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int stage = 0; stage < 2; ++stage) {
+        vae_wgrad_job jobs[VAE_MAX_WGRAD_JOBS];
+        int idx[VAE_MAX_WGRAD_JOBS], nj = 0;
+        for (int i = 0; i < 7; ++i) {
+            const int b = (i + 1) / 2;
+            const int h = d.S >> b;
+            if ((b >= 2) != (stage == 0) || !vae_conv3_wgrad_patch_ok(h, h, CONV_CI[i], CONV_CO[i])) continue;
+            jobs[nj] = vae_wgrad_job{nullptr, nullptr, nullptr, d.N, h, h, CONV_CI[i], CONV_CO[i], 0};
+            idx[nj++] = i;
+        }
+        int ns[VAE_MAX_WGRAD_JOBS];
+        if (nj > 0 && vae_conv3_wgrad_multi_plan(jobs, nj, 256, ns) == 0)
+            for (int k = 0; k < nj; ++k) batched_ns[idx[k]] = ns[k];
+    }
     for (int i = 0; i < 7; ++i) {
         const int b = (i + 1) / 2;     // encoder block of conv i (c1b -> 0, c2a,c2b -> 1, ...)
         const long h = d.S >> b;
         long v = slab_need(CONV_CO[i], CONV_CI[i], 9, (long)d.N * h * h);
         if (vae_conv3_wgrad_patch_ok((int)h, (int)h, CONV_CI[i], CONV_CO[i])) {
+            // either form of the launch: one layer at a time, or the stage's layers together
             const long vp = (long)vae_conv3_wgrad_patch_ksplit(d.N, (int)h, (int)h, CONV_CI[i], CONV_CO[i]) * 9 * CONV_CO[i] * CONV_CI[i];
             if (vp > v) v = vp;
+            const long vb = (long)batched_ns[i] * 9 * CONV_CO[i] * CONV_CI[i];
+            if (vb > v) v = vb;
         }
         s += up64(v);
     }
@@ -430,6 +451,11 @@ struct Fork {
     int njobs;
     long slab_used;      // floats
     bool defer;          // whole backward pass in one call: every fold waits for ONE launch at its end
+    // conv3x3 weight gradients wait for the end of the backward stage too: ONE launch computes them all (its
+    // workgroups dealt out over the layers), so the stage writes one chip-full of split-K slabs instead of one per layer
+    vae_wgrad_job wj[VAE_MAX_WGRAD_JOBS];
+    float* wj_out[VAE_MAX_WGRAD_JOBS];
+    int nwj;
 };
 
 static const int N_EVENTS = 64;
@@ -459,6 +485,7 @@ static int fork_init(Fork* f, void* main, void* side) {
     f->njobs = 0;
     f->slab_used = 0;
     f->defer = false;
+    f->nwj = 0;
     f->ev = f->two ? event_pool() : nullptr;
     CHECK(!f->two || f->ev, "vae_model_backward: could not create the events that order the two streams");
     return 0;
@@ -530,6 +557,47 @@ static int conv3_wgrad_to(const Ctx& c, Fork* f, float** slab_out, const void* d
         return vae_conv3_wgrad_patch(dy, x, *slab_out, c.d.N, H, H, Ci, Co, ns, stream);
     }
     return wgrad_to(c, f, slab_out, dy, x, Co, Ci, (long)c.d.N * H * H, Co, Ci, VAE_WGRAD_CONV3, H, H, 9, nsplit_out, stream);
+}
+
+static bool wgrad_batched(int H, int Ci, int Co) { return vae::g_wgrad_batch_mode == 0 && vae_conv3_wgrad_patch_ok(H, H, Ci, Co); }
+
+// Conv2d 3x3 weight gradient of one layer into grad_out ([Co][Ci][3][3]): queued for the stage's single launch when the
+// patch kernel covers the geometry (dy must then stay untouched until flush_wgrads), else launched now
+static int conv3_wgrad(const Ctx& c, Fork* f, const void* dy, const void* x, int Co, int Ci, int H, float* grad_out, void* stream,
+                       bool* queued) {
+    *queued = wgrad_batched(H, Ci, Co);
+    if (*queued) {
+        CHECK(f->nwj < VAE_MAX_WGRAD_JOBS, "vae_model_backward: too many pending weight gradients");
+        vae_wgrad_job& q = f->wj[f->nwj];
+        q.dy = dy; q.x = x; q.slab = nullptr; q.n_img = c.d.N; q.H = H; q.W = H; q.Cin = Ci; q.Cout = Co; q.nsplit = 0;
+        f->wj_out[f->nwj++] = grad_out;
+        return 0;
+    }
+    int ns = 1;
+    float* slab = nullptr;
+    TRY(conv3_wgrad_to(c, f, &slab, dy, x, Co, Ci, H, &ns, stream));
+    // slab [co][tap][ci] -> Conv2d weight [co][ci][tap]
+    return fold_later(f, slab, ns, 9L * Co * Ci, 0, grad_out, Co, 9, Ci, 1, 9L * Ci, 1, 9, 0);
+}
+
+// the stage's pending weight gradients: plan the K splits, ONE launch, their folds recorded for the stage's fold launch
+static int flush_wgrads(const Ctx& c, Fork* f) {
+    if (f->nwj == 0) return 0;
+    int ns[VAE_MAX_WGRAD_JOBS];
+    TRY(vae_conv3_wgrad_multi_plan(f->wj, f->nwj, 256, ns));
+    for (int i = 0; i < f->nwj; ++i) {
+        vae_wgrad_job& q = f->wj[i];
+        q.nsplit = ns[i];
+        TRY(slab_take(c, f, (long)ns[i] * 9 * q.Cout * q.Cin, &q.slab));
+    }
+    TRY(side_after_main(f));
+    TRY(vae_conv3_wgrad_patch_multi(f->wj, f->nwj, f->side));
+    for (int i = 0; i < f->nwj; ++i) {
+        const vae_wgrad_job& q = f->wj[i];
+        TRY(fold_later(f, q.slab, q.nsplit, 9L * q.Cout * q.Cin, 0, f->wj_out[i], q.Cout, 9, q.Cin, 1, 9L * q.Cin, 1, 9, 0));
+    }
+    f->nwj = 0;
+    return 0;
 }
 
 // stage 0: head .. fc heads (everything after the encoder); leaves d(encoder output) in gradient buffer 0
@@ -634,6 +702,8 @@ static int backward_decoder(const Ctx& c, Fork* f, const float* d_recon, const f
 
 // encoder block b: expects d(block output) in buffer (3 - b) % 3, leaves d(block input) in the next one.
 // *w_carry: the previous block's last wgrad (it reads the buffer this block's first dgrad overwrites).
+// The gradients of the block's two conv outputs go to buffers of their own when their weight gradients wait for the
+// stage's single launch (they must outlive the block), else into the rotation as before.
 static int backward_block(const Ctx& c, Fork* f, int b, const void* const* masks, hipEvent_t* w_carry) {
     const Dims& d = c.d;
     const WsLayout& w = c.ws;
@@ -643,23 +713,24 @@ static int backward_block(const Ctx& c, Fork* f, int b, const void* const* masks
     void* sd = f->side;
     int ns = 1;
     const double p = c.cfg->p_dropout;
-    // second conv + BN + ReLU + dropout (+ pool): a -> b
+    const int Ci = b ? ENC_C[b - 1] : d.Cin;
+    void* dyb = wgrad_batched(H, C, C) ? c.at(w.dyb[b]) : c.at(w.g[ib]);
+    void* dya = b > 0 && wgrad_batched(H, Ci, C) ? c.at(w.dya[b]) : c.at(w.g[ia]);
+    // second conv + BN + ReLU + dropout (+ pool): a -> dyb
     TRY(vae_bn_act_bwd_route_y(c.at(w.g[ia]), c.at(w.yb[b]), c.coef(2 * b + 1, 0), c.coef(2 * b + 1, 1), c.coef(2 * b + 1, 2),
-                             c.coef(2 * b + 1, 3), (float*)c.at(w.bnpart), c.G(8 * b + 6), c.at(w.g[ib]),
+                             c.coef(2 * b + 1, 3), (float*)c.at(w.bnpart), c.G(8 * b + 6), dyb,
                              b < 3 ? c.at(w.route[b]) : nullptr, b < 3 && vae::g_pool_ymax_mode == 0 ? c.at(w.ymax[b]) : nullptr, d.N, H, H, C, b < 3, p,
                              masks ? masks[b] : nullptr,
                              c.cfg->seed, c.cfg->step, VAE_STREAM_DROPOUT0 + b, c.cfg->rank, c.stream));
     TRY(side_after_main(f));
-    float* slab = nullptr;
-    TRY(conv3_wgrad_to(c, f, &slab, c.at(w.g[ib]), c.at(w.aa[b]), C, C, H, &ns, sd));
-    // slab [co][tap][ci] -> Conv2d weight [co][ci][tap]
-    TRY(fold_later(f, slab, ns, 9L * C * C, 0, c.G(8 * b + 4), C, 9, C, 1, 9L * C, 1, 9, 0));
-    hipEvent_t w1;
-    TRY(side_mark(f, &w1));
+    bool queued = false;
+    TRY(conv3_wgrad(c, f, dyb, c.at(w.aa[b]), C, C, H, c.G(8 * b + 4), sd, &queued));
+    hipEvent_t w1 = nullptr;
+    if (!queued) TRY(side_mark(f, &w1));
     TRY(main_after(f, *w_carry));       // buffer c was read by the previous block's second wgrad
-    TRY(vae_conv3x3_gemm(c.at(w.g[ib]), c.pk_at(c.pk.conv_d[2 * b]), nullptr, c.at(w.g[ic]), nullptr, nullptr, d.N, H, H, C, C,
+    TRY(vae_conv3x3_gemm(dyb, c.pk_at(c.pk.conv_d[2 * b]), nullptr, c.at(w.g[ic]), nullptr, nullptr, d.N, H, H, C, C,
                          c.stream));
-    // first conv + BN + ReLU: c -> a
+    // first conv + BN + ReLU: c -> dya
     if (b == 0 && conv1_one_pass(d)) {
         // nothing needs the first conv's input gradient: BatchNorm backward and weight gradient in one pass, no tensor written
         float* scratch = nullptr;
@@ -670,20 +741,20 @@ static int backward_block(const Ctx& c, Fork* f, int b, const void* const* masks
         return side_mark(f, w_carry);
     }
     TRY(vae_bn_act_bwd(c.at(w.g[ic]), c.at(w.ya[b]), c.coef(2 * b, 0), c.coef(2 * b, 1), c.coef(2 * b, 2), c.coef(2 * b, 3),
-                       (float*)c.at(w.bnpart), c.G(8 * b + 2), c.at(w.g[ia]), d.N, H, H, C, 0, 0.0, nullptr, 0, 0, 0, 0, c.stream));
+                       (float*)c.at(w.bnpart), c.G(8 * b + 2), dya, d.N, H, H, C, 0, 0.0, nullptr, 0, 0, 0, 0, c.stream));
     TRY(side_after_main(f));
     if (b == 0) {
-        TRY(wgrad_to(c, f, &slab, c.at(w.g[ia]), c.at(w.x8), C, 64, M, C, 8, VAE_WGRAD_CONV3_C8, H, H, 2, &ns, sd));
+        float* slab = nullptr;
+        TRY(wgrad_to(c, f, &slab, dya, c.at(w.x8), C, 64, M, C, 8, VAE_WGRAD_CONV3_C8, H, H, 2, &ns, sd));
         // slab [co][16 taps][8 ch] (taps >= 9, channels >= Cin are padding) -> weight [co][ci][tap]
         TRY(fold_later(f, slab, ns, 64L * 128, 0, c.G(0), 64, 16, 8, 1, 9L * d.Cin, 1, 9, 0, 9, d.Cin));
         return side_mark(f, w_carry);
     }
-    const int Ci = ENC_C[b - 1];
-    TRY(conv3_wgrad_to(c, f, &slab, c.at(w.g[ia]), c.at(w.ob[b - 1]), C, Ci, H, &ns, sd));
-    TRY(fold_later(f, slab, ns, 9L * C * Ci, 0, c.G(8 * b), C, 9, Ci, 1, 9L * Ci, 1, 9, 0));
-    TRY(side_mark(f, w_carry));
+    TRY(conv3_wgrad(c, f, dya, c.at(w.ob[b - 1]), C, Ci, H, c.G(8 * b), sd, &queued));
+    if (queued) *w_carry = nullptr;
+    else TRY(side_mark(f, w_carry));
     TRY(main_after(f, w1));             // buffer b is still read by this block's first wgrad
-    return vae_conv3x3_gemm(c.at(w.g[ia]), c.pk_at(c.pk.conv_d[2 * b - 1]), nullptr, c.at(w.g[ib]), nullptr, nullptr, d.N, H, H,
+    return vae_conv3x3_gemm(dya, c.pk_at(c.pk.conv_d[2 * b - 1]), nullptr, c.at(w.g[ib]), nullptr, nullptr, d.N, H, H,
                             C, Ci, c.stream);
 }
 
@@ -710,11 +781,13 @@ extern "C" int vae_model_backward(const vae_model_cfg* cfg, const float* params,
     if (stage == -1 || stage == 1) {
         TRY(backward_block(c, &f, 3, keep_masks, &carry));
         TRY(backward_block(c, &f, 2, keep_masks, &carry));
+        TRY(flush_wgrads(c, &f));
         TRY(flush_folds(&f));
     }
     if (stage == -1 || stage == 2) {
         TRY(backward_block(c, &f, 1, keep_masks, &carry));
         TRY(backward_block(c, &f, 0, keep_masks, &carry));
+        TRY(flush_wgrads(c, &f));
         TRY(flush_folds(&f, true));
     }
     // join: whatever the caller enqueues next on `stream` (all-reduce of this stage, the optimizer) sees every gradient
