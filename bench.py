@@ -67,7 +67,7 @@ def family(name):
 # share of a step that "conv3x3 forward + input gradient" takes is the sum over all three of its kernels.
 ROLES = (
     ("conv3x3 fwd+dgrad (conv3_wide + conv3_ws64 + conv3_patch_tn)", ("conv3_wide_kernel", "conv3_ws64_kernel", "conv3_patch_tn_kernel")),
-    ("conv3x3 wgrad (conv3_wgrad_patch)", ("conv3_wgrad_patch_kernel",)),
+    ("conv3x3 wgrad (conv3_wgrad_patch)", ("conv3_wgrad_patch_kernel", "conv3_wgrad_pc_kernel", "conv3_wgrad_multi_kernel")),
     ("batchnorm bwd (bn_act_bwd + bn_bwd_conv1)", ("bn_act_bwd(reduce+apply)", "bn_bwd_conv1_kernel")),
     ("batchnorm fwd (bn_act_fwd)", ("bn_act_fwd_kernel",)),
 )

@@ -186,7 +186,7 @@ def test_batched_weight_gradient_plan(n, size, max_wgs):
     workgroup per output tile, the launch stays within the workgroup budget whenever the tiles alone fit in it, no split
     is empty, and K tiles per workgroup are even across layers (within a factor of two of each other where a layer
     has enough of them to split)"""
-    geo = [(size // 8, 256, 256), (size // 8, 128, 256), (size // 4, 128, 128), (size // 4, 64, 128), (size // 2, 64, 64)]
+    geo = [(size // 8, 256, 256), (size // 8, 256, 256), (size // 4, 256, 256), (size // 4, 128, 256), (size // 2, 128, 128)]
     jobs = (L.WgradJob * len(geo))()
     for q, (H, Ci, Co) in zip(jobs, geo):
         q.n_img, q.H, q.W, q.Cin, q.Cout = n, H, H, Ci, Co

@@ -144,8 +144,8 @@ def _check_conv3x3_wgrad_patch(L, n, H, W, Ci, Co, ns):
 
 def _stage_jobs(n, size):
     """(H, Ci, Co) of the conv3x3 layers VAEConv's backward hands to one launch: blocks 3 + 2, then blocks 1 + 0."""
-    return ([(size // 8, 256, 256), (size // 8, 128, 256), (size // 4, 128, 128), (size // 4, 64, 128)],
-            [(size // 2, 64, 64), (size // 2, 64, 64), (size, 64, 64)])
+    return ([(size // 8, 256, 256), (size // 8, 256, 256), (size // 4, 256, 256), (size // 4, 128, 256)],
+            [(size // 2, 128, 128), (size // 2, 64, 128), (size, 64, 64)])
 
 
 @pytest.mark.parametrize("n,size,max_wgs", [(16, 32, 256), (3, 32, 256), (8, 64, 256), (64, 32, 64), (5, 32, 8)])
