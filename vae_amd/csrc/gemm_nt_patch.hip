@@ -332,7 +332,8 @@ constexpr int PC_STAGE = 64 * ROWB + PATCH_ROWS_MAX * ROWB, PC_SMEM_BYTES = 4 * 
 static_assert(PC_SMEM_BYTES <= 160 * 1024 && 4 * 64 * 16 * 16 <= PC_SMEM_BYTES, "LDS");
 
 // the workgroup's job: weight block (ci from n0, co from m0) of problem p, K tiles [split * kps, + kps)
-template <int W>
+// ABL (diagnostic builds only, -DVAE_ABLATE): bit 0 no matrix instructions, bit 1 no copies, bit 2 no fragment reads
+template <int W, int ABL = 0>
 __device__ __forceinline__ void wgrad_pc_body(const PatchP& p, int n0, int m0, int split, unsigned char* smem) {
     constexpr int W2 = W + 2;
     constexpr int QD = 2;     // input fragments requested ahead (4 measured: 10 % slower)
@@ -365,6 +366,7 @@ __device__ __forceinline__ void wgrad_pc_body(const PatchP& p, int n0, int m0, i
         __builtin_amdgcn_make_buffer_rsrc((void*)p.Q, 0, (int)((unsigned)p.Ktot * (unsigned)p.Ci * 2u), 0x00020000);
     // a tile past the range is all zero fill
     auto stage = [&](int buf, int kt) {
+        if (ABL & 2) return;
         unsigned char* pbase = smem + buf * STAGE;
         unsigned char* qbase = pbase + P_BYTES;
         const int k0 = kt * 64;
@@ -457,6 +459,7 @@ __device__ __forceinline__ void wgrad_pc_body(const PatchP& p, int n0, int m0, i
             auto q_frag = [&](int s) -> bf16x8 {
                 const int tl = s / 18, kk = (s / 9) & 1, t = s % 9, dh = t / 3, dw = t % 3;
                 const unsigned lo = qb[kk][0][dw], hi = qb[kk][1][dw];
+                if (ABL & 4) return __builtin_bit_cast(bf16x8, make_uint4(lo, hi, lo, hi));
                 if (tl == 0) {
                     if (dh == 0) return tr_pair_off<0>(lo, hi);
                     if (dh == 1) return tr_pair_off<W2 * ROWB>(lo, hi);
@@ -476,7 +479,8 @@ __device__ __forceinline__ void wgrad_pc_body(const PatchP& p, int n0, int m0, i
                         asm volatile("v_xor_b32 %0, %1, %2" : "=v"(alo) : "n"(j << 5), "v"(pbs[kk][0]));
                         asm volatile("v_xor_b32 %0, %1, %2" : "=v"(ahi) : "n"(j << 5), "v"(pbs[kk][1]));
                     }
-                    pb[kk][j] = half < 2 ? tr_pair_off<0>(alo, ahi) : tr_pair_off<STAGE>(alo, ahi);
+                    if (ABL & 4) pb[kk][j] = __builtin_bit_cast(bf16x8, make_uint4(alo, ahi, alo, ahi));
+                    else pb[kk][j] = half < 2 ? tr_pair_off<0>(alo, ahi) : tr_pair_off<STAGE>(alo, ahi);
                 }
             };
             bf16x8 qa[QD + 1];
@@ -503,7 +507,9 @@ __device__ __forceinline__ void wgrad_pc_body(const PatchP& p, int n0, int m0, i
                 if (half < 3 && t >= TA && t <= TA + QD) newer += 4;
                 if (half < 3 && t >= TB && t <= TB + QD) newer += 4;
                 frag_wait_n(newer > 15 ? 15 : newer, qa[st % (QD + 1)]);
-                if (st < 18 || two) {
+                if (ABL & 1) {      // keep the fragments alive without the matrix pipe
+                    if (st == 35) acc[0][0][0] += __builtin_bit_cast(f32x4, __builtin_bit_cast(uint4, qa[st % (QD + 1)]) ^ __builtin_bit_cast(uint4, pb[half & 1][0]))[0];
+                } else if (st < 18 || two) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[st % (QD + 1)], pb[half & 1][j], acc[t][j], 0, 0, 0);
@@ -545,6 +551,14 @@ __global__ __launch_bounds__(512, 1) void conv3_wgrad_pc_kernel(const PatchP p) 
     __shared__ __attribute__((aligned(16))) unsigned char smem[PC_SMEM_BYTES];
     wgrad_pc_body<W>(p, blockIdx.x * 64, blockIdx.y * 64, blockIdx.z, smem);
 }
+#ifdef VAE_ABLATE
+template <int ABL>
+__global__ __launch_bounds__(512, 1) void conv3_wgrad_pc_abl_kernel(const PatchP p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[PC_SMEM_BYTES];
+    wgrad_pc_body<32, ABL>(p, blockIdx.x * 64, blockIdx.y * 64, blockIdx.z, smem);
+}
+#endif
+int g_wgrad_ablate = 0;       // diagnostic builds: which parts of the 32-wide producer / consumer kernel are left out
 
 // Several weight gradients in ONE launch.  Every 512-thread workgroup of these kernels keeps a 64 x 9 x 64 fp32 accumulator
 // tile (147 KB) and leaves it as a split-K slab, so a launch that fills the 256 CUs writes 37.7 MB of slabs whatever the
@@ -569,6 +583,9 @@ __global__ __launch_bounds__(512, 1) void conv3_wgrad_multi_kernel(const WgradJo
         if ((int)blockIdx.x >= jobs.j[i].wg0) ji = i;       // uniform over the workgroup
     const WgradJob& jb = jobs.j[ji];
     const int local = (int)blockIdx.x - jb.wg0;
+    // tiles fastest.  (Measured and not kept: blocks of 8 K ranges x all tiles with the K range fastest, so that the
+    // tiles of a range -- which read the same dY and X rows -- share one XCD's L2: the step +0.5 % at batch 512, equal at
+    // the 64-wide configuration; the re-reads are served by the memory-side cache either way.)
     const int nxi = local % jb.nx, t = local / jb.nx, nyi = t % jb.ny, split = t / jb.ny;
     switch (jb.W) {
         case 4: wgrad_pc_body<4>(jb.p, nxi * 64, nyi * 64, split, smem); break;
@@ -658,6 +675,21 @@ extern "C" int vae_conv3_wgrad_patch(const void* dy, const void* x, float* slab,
     const double flops = 2.0 * Cout * Cin * 9.0 * p.Ktot;
     const double bytes = 2.0 * p.Ktot * ((double)Cout + Cin) + 4.0 * nsplit * 9.0 * Cout * Cin;
     ProfScope prof("conv3_wgrad_patch_kernel", flops, bytes, s);
+#ifdef VAE_ABLATE
+    if (g_wgrad_ablate && W == 32) {
+        switch (g_wgrad_ablate) {
+            case 1: hipLaunchKernelGGL(conv3_wgrad_pc_abl_kernel<1>, grid, dim3(512), 0, s, p); break;
+            case 2: hipLaunchKernelGGL(conv3_wgrad_pc_abl_kernel<2>, grid, dim3(512), 0, s, p); break;
+            case 3: hipLaunchKernelGGL(conv3_wgrad_pc_abl_kernel<3>, grid, dim3(512), 0, s, p); break;
+            case 4: hipLaunchKernelGGL(conv3_wgrad_pc_abl_kernel<4>, grid, dim3(512), 0, s, p); break;
+            case 5: hipLaunchKernelGGL(conv3_wgrad_pc_abl_kernel<5>, grid, dim3(512), 0, s, p); break;
+            case 6: hipLaunchKernelGGL(conv3_wgrad_pc_abl_kernel<6>, grid, dim3(512), 0, s, p); break;
+            default: hipLaunchKernelGGL(conv3_wgrad_pc_abl_kernel<7>, grid, dim3(512), 0, s, p); break;
+        }
+        VAE_LAUNCH_CHECK("conv3_wgrad_pc_abl_kernel");
+        return 0;
+    }
+#endif
 #define GO(WW)                                                                                          \
     if (wgrad_use_pc(p.kps)) hipLaunchKernelGGL(conv3_wgrad_pc_kernel<WW>, grid, dim3(512), 0, s, p);      \
     else hipLaunchKernelGGL(conv3_wgrad_patch_kernel<WW>, grid, dim3(512), 0, s, p)
