@@ -72,7 +72,9 @@ int vae_prof_stop(char* names, int* launches, double* total_ms, double* flops, d
  * (default), 1 a finishing kernel does; "convt_bwd" = 0 the 64 -> 64 ConvTranspose backward as one kernel that also makes the head's gradient
  * on the way (default), 1 as separate input- and weight-gradient kernels, 2 one kernel reading the stored gradient; "wgrad_batch" = 0
  * vae_model_backward computes the conv3x3 weight gradients of a backward stage in ONE launch (vae_conv3_wgrad_patch_multi: a seventh
- * of the split-K slab traffic; default), 1 one launch per layer.  Unknown keys and
+ * of the split-K slab traffic; default), 1 one launch per layer; "wgrad_ablate" = 0..7, only in a library built with
+ * -DVAE_ABLATE (a no-op otherwise): vae_conv3_wgrad_patch on 32-wide images runs without its matrix instructions (bit 0),
+ * its copies (bit 1), its fragment reads (bit 2) -- wrong results, for timing what bounds the kernel.  Unknown keys and
  * values outside a key's range are rejected.  Not thread-safe: set it while nothing is being launched, and never
  * between a vae_model_forward and its vae_model_backward: some keys change the workspace carving that
  * vae_model_workspace_bytes and both passes derive from the config. */
