@@ -72,7 +72,9 @@ int vae_prof_stop(char* names, int* launches, double* total_ms, double* flops, d
  * (default), 1 a finishing kernel does; "convt_bwd" = 0 the 64 -> 64 ConvTranspose backward as one kernel that also makes the head's gradient
  * on the way (default), 1 as separate input- and weight-gradient kernels, 2 one kernel reading the stored gradient; "wgrad_batch" = 0
  * vae_model_backward computes the conv3x3 weight gradients of a backward stage in ONE launch (vae_conv3_wgrad_patch_multi: a seventh
- * of the split-K slab traffic; default), 1 one launch per layer; "wgrad_ablate" = 0..7, only in a library built with
+ * of the split-K slab traffic; default), 1 one launch per layer; "conv1_twice" = 0 the whole-model passes
+ * convolve the first layer twice and never store its output (vae_conv3x3_c8_stats / _bn_act / vae_bn_bwd_conv1_bits; default, needs
+ * "conv1_bwd" = 0), 1 they store it; "wgrad_ablate" = 0..7, only in a library built with
  * -DVAE_ABLATE (a no-op otherwise): vae_conv3_wgrad_patch on 32-wide images runs without its matrix instructions (bit 0),
  * its copies (bit 1), its fragment reads (bit 2) -- wrong results, for timing what bounds the kernel.  Unknown keys and
  * values outside a key's range are rejected.  Not thread-safe: set it while nothing is being launched, and never
@@ -172,6 +174,19 @@ int vae_conv3x3_c8_gemm(const void* x8, const void* w_packed, const float* bias,
                         void* stream);
 /* partial-statistics rows it writes (of Cout floats each); never more than vae_gemm_stat_rows(n*H*W, Cout) */
 int vae_conv3x3_c8_stat_rows(int n_img, int H, int W, int Cout);
+/* The same first conv followed by its BatchNorm2d + ReLU (vae/models/vae.py:129-131, the first three modules of the
+ * first DoubleConv) as TWO passes over x8 that never store the conv output: the input is 16 bytes per pixel and the
+ * output 2 * Cout, so convolving twice is cheaper than writing the conv output and reading it back.
+ *   vae_conv3x3_c8_stats  -- the statistics rows of vae_conv3x3_c8_gemm (same values, same row count), nothing else;
+ *   vae_conv3x3_c8_bn_act -- out [n,H,W,Cout] = relu(bf16(conv) * scale + shift), bit for bit what vae_bn_act_fwd makes of
+ *                            the conv output vae_conv3x3_c8_gemm stores; relu_bits (optional): [n*H*W][Cout / 8] bytes, bit
+ *                            (c & 7) of byte (c >> 3) of a pixel set where channel c passed the ReLU (for vae_bn_bwd_conv1_bits).
+ * vae_conv3x3_c8_twice_ok: 1 when the geometry is covered (power-of-two images, Cout a multiple of 64, pixels a multiple of 32). */
+int vae_conv3x3_c8_twice_ok(int n_img, int H, int W, int Cout);
+int vae_conv3x3_c8_stats(const void* x8, const void* w_packed, const float* bias, float* stat_sum, float* stat_sq,
+                         int n_img, int H, int W, int Cout, void* stream);
+int vae_conv3x3_c8_bn_act(const void* x8, const void* w_packed, const float* bias, const float* scale, const float* shift,
+                          void* out, void* relu_bits, int n_img, int H, int W, int Cout, void* stream);
 /* nn.ConvTranspose2d(Cin, Cout, 2, stride=2) forward, vae/models/vae.py:64,67,70.
  * x [n,H,W,Cin], w_packed [(kh,kw,co)][Cin], y [n,2H,2W,Cout]; stats are per GEMM column
  * (tap*Cout + co), 4*Cout of them. */
@@ -358,6 +373,15 @@ long vae_bn_bwd_conv1_scratch_floats(int n_img, int H, int W);
 int vae_bn_bwd_conv1(const void* gin, const void* y, const void* x8, const float* scale, const float* shift,
                      const float* mean, const float* rstd, float* scratch, float* sums, float* dW, int n_img,
                      int H, int W, int Cin, void* stream);
+/* The same backward (vae/models/vae.py:24-31,34) when the forward ran the first conv in two passes and never stored its
+ * output: relu_bits [n*H*W][8] (vae_conv3x3_c8_bn_act) holds the ReLU decisions, and each 64-pixel tile's y is rebuilt
+ * on the matrix pipe from the tile's shifted-input rows and the conv's own parameters w [64][Cin][3][3] / bias [64]
+ * (fp32, rounded to bf16 as the forward's operand pack rounds them).  A rebuilt y can differ from the forward's in its
+ * last bf16 bit (other order of the 27 products); it only enters sums over all pixels.  scale / mean / rstd, scratch,
+ * sums and dW as above. */
+int vae_bn_bwd_conv1_bits(const void* gin, const void* relu_bits, const void* x8, const float* w, const float* bias,
+                          const float* scale, const float* mean, const float* rstd, float* scratch, float* sums,
+                          float* dW, int n_img, int H, int W, int Cin, void* stream);
 /* ---- GroupNorm form of the double-conv block: nn.GroupNorm(8, C) + ReLU (+ nn.Dropout) (+ nn.MaxPool2d(2)),
  *      vae/practice/vae_conv.py:20-36,50-59 and vae/practice/vae_original.py:58-74 ----------------------------
  * y [n,H,W,C] bf16 (a conv output) -> out [n,H,W,C] or, with pool, [n,H/2,W/2,C].  Statistics are per image and

@@ -123,3 +123,60 @@ def test_one_pass_rejects_what_it_cannot_hold(L):
         L.call("vae_bn_bwd_conv1", L.ptr(gd), L.ptr(yd), None, *[L.ptr(t) for t in co], L.ptr(scratch), L.ptr(out), L.ptr(dw),
                1, 8, 8, 3, L.current_stream())
     assert L.call("vae_bn_bwd_conv1_scratch_floats", 0, 8, 8) == -1
+
+
+@pytest.mark.parametrize("n,H,W,Cin", [(8, 32, 32, 3), (2, 16, 16, 2), (1, 8, 8, 3), (96, 32, 32, 3), (3, 16, 32, 1), (5, 8, 8, 3)])
+def test_bits_form_without_the_stored_conv_output(L, n, H, W, Cin):
+    """forward in two passes (vae_conv3x3_c8_stats / _bn_act: the conv output is never stored, one ReLU bit per element
+    is), backward from the bits with y rebuilt per tile: d gamma, d beta and dW against the stored-output kernel on the
+    SAME conv output (1e-4: a rebuilt y may differ in its last bf16 bit) and against the fp64 formulas; reproducible;
+    includes a last tile that is not full (320 pixels) and workgroups that walk several tiles"""
+    g = torch.Generator().manual_seed(31 * n + H + Cin)
+    x = torch.rand(n, Cin, H, W, generator=g)
+    w = (torch.randn(64, Cin, 3, 3, generator=g) / 3)
+    b = torch.randn(64, generator=g) / 2
+    gin = (torch.randn(n, 64, H, W, generator=g) * 1e-3 + 2e-4).to(torch.bfloat16)
+    s = L.current_stream()
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    x8 = torch.zeros(n, H, W, 8, device=DEV, dtype=torch.bfloat16)
+    L.call("vae_nchw_to_nhwc8", L.ptr(xd), L.ptr(x8), n, Cin, H, W, s)
+    wp = torch.zeros(64, 16, 8, device=DEV, dtype=torch.bfloat16)
+    L.call("vae_pack_bf16", L.ptr(wd), L.ptr(wp), L.long4(64, Cin, 9, 1), L.long4(128, 1, 8, 0), 0, s)
+    rows = L.call("vae_conv3x3_c8_stat_rows", n, H, W, 64)
+    ssum, ssq = torch.empty(rows, 64, device=DEV), torch.empty(rows, 64, device=DEV)
+    y = torch.empty(n, H, W, 64, device=DEV, dtype=torch.bfloat16)
+    L.call("vae_conv3x3_c8_gemm", L.ptr(x8), L.ptr(wp), L.ptr(bd), L.ptr(y), L.ptr(ssum), L.ptr(ssq), n, H, W, 64, s)
+    gam, bet = (torch.rand(64, generator=g) + 0.5).to(DEV), (torch.randn(64, generator=g) * 0.3).to(DEV)
+    coef = torch.empty(4, 64, device=DEV)
+    L.call("vae_bn_finalize", L.ptr(ssum), L.ptr(ssq), rows, 64, 1, float(n * H * W), L.ptr(gam), L.ptr(bet), None, None, 0.1, 1e-5, 0,
+           L.ptr(coef[0]), L.ptr(coef[1]), L.ptr(coef[2]), L.ptr(coef[3]), s)
+    act = torch.empty_like(y)
+    bits = torch.empty(n * H * W, 8, device=DEV, dtype=torch.uint8)
+    L.call("vae_conv3x3_c8_bn_act", L.ptr(x8), L.ptr(wp), L.ptr(bd), L.ptr(coef[0]), L.ptr(coef[1]), L.ptr(act), L.ptr(bits), n, H, W, 64, s)
+    gd = nhwc(gin).to(DEV)
+    nf = L.call("vae_bn_bwd_conv1_scratch_floats", n, H, W)
+
+    def stored():
+        scratch, sums, dW = torch.full((nf,), float("nan"), device=DEV), torch.full((128,), float("nan"), device=DEV), torch.full((64, Cin, 3, 3), float("nan"), device=DEV)
+        L.call("vae_bn_bwd_conv1", L.ptr(gd), L.ptr(y), L.ptr(x8), L.ptr(coef[0]), L.ptr(coef[1]), L.ptr(coef[2]), L.ptr(coef[3]),
+               L.ptr(scratch), L.ptr(sums), L.ptr(dW), n, H, W, Cin, s)
+        return sums.cpu(), dW.cpu()
+
+    def from_bits():
+        scratch, sums, dW = torch.full((nf,), float("nan"), device=DEV), torch.full((128,), float("nan"), device=DEV), torch.full((64, Cin, 3, 3), float("nan"), device=DEV)
+        L.call("vae_bn_bwd_conv1_bits", L.ptr(gd), L.ptr(bits), L.ptr(x8), L.ptr(wd), L.ptr(bd), L.ptr(coef[0]), L.ptr(coef[2]), L.ptr(coef[3]),
+               L.ptr(scratch), L.ptr(sums), L.ptr(dW), n, H, W, Cin, s)
+        return sums.cpu(), dW.cpu()
+
+    s0, w0 = stored()
+    s1, w1 = from_bits()
+    assert rel_l2(s1[:64], s0[:64]) <= 1e-4 and rel_l2(w1, w0) <= 1e-4
+    assert torch.equal(s1[64:], s0[64:])                                     # sum d: the same d, the same order
+    s2, w2 = from_bits()
+    assert torch.equal(s1, s2) and torch.equal(w1, w2)
+    # and against the fp64 formulas on the stored conv output
+    yc = y.float().cpu().permute(0, 3, 1, 2).to(torch.bfloat16)
+    c = coef.cpu()
+    s_dx, s_d, dW_ref, _ = reference(x, yc, gin, c[0], c[1], c[2], c[3])
+    assert rel_l2(s1[:64], s_dx.float()) <= 1e-4 and rel_l2(s1[64:], s_d.float()) <= 1e-5
+    assert rel_l2(w1, dW_ref.float()) <= 1e-4

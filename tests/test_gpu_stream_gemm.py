@@ -74,6 +74,59 @@ def test_first_conv_streaming_equals_torch_and_the_tiled_kernel(L, n, H, W, Ci, 
     assert (out[0] != out[1]).float().mean().item() < 0.02
 
 
+@pytest.mark.parametrize("n,H,W,Ci,Co", [(2, 8, 8, 3, 64), (3, 32, 32, 3, 64), (1, 4, 8, 1, 64), (96, 32, 32, 3, 64),
+                                         (5, 16, 16, 3, 128), (2, 8, 16, 8, 256)])
+def test_first_conv_in_two_passes_equals_conv_then_batchnorm(L, n, H, W, Ci, Co):
+    """statistics-only pass == the statistics rows of the storing kernel, bit for bit; the BatchNorm + ReLU pass ==
+    vae_bn_act_fwd applied to the stored conv output, bit for bit; the ReLU bits say where the activation is positive"""
+    assert L.call("vae_conv3x3_c8_twice_ok", n, H, W, Co) == 1
+    g = torch.Generator().manual_seed(n + H + 7)
+    x8 = torch.zeros(n, H, W, 8, dtype=torch.bfloat16)
+    x8[..., :Ci] = torch.rand(n, H, W, Ci, generator=g).to(torch.bfloat16)
+    x8 = x8.to(DEV)
+    wp = torch.zeros(Co, 16, 8, dtype=torch.bfloat16)
+    wp[:, :9, :Ci] = (torch.randn(Co, 9, Ci, generator=g) / 5).to(torch.bfloat16)
+    wp = wp.to(DEV)
+    bd = torch.randn(Co, generator=g).to(DEV)
+    rows = L.call("vae_conv3x3_c8_stat_rows", n, H, W, Co)
+    y = torch.full((n, H, W, Co), float("nan"), device=DEV, dtype=torch.bfloat16)
+    ssum, ssq = torch.full((rows, Co), float("nan"), device=DEV), torch.full((rows, Co), float("nan"), device=DEV)
+    s = L.current_stream()
+    L.call("vae_conv3x3_c8_gemm", L.ptr(x8), L.ptr(wp), L.ptr(bd), L.ptr(y), L.ptr(ssum), L.ptr(ssq), n, H, W, Co, s)
+    s1, q1 = torch.full_like(ssum, float("nan")), torch.full_like(ssq, float("nan"))
+    L.call("vae_conv3x3_c8_stats", L.ptr(x8), L.ptr(wp), L.ptr(bd), L.ptr(s1), L.ptr(q1), n, H, W, Co, s)
+    assert torch.equal(s1, ssum) and torch.equal(q1, ssq)
+    gam, bet = (torch.rand(Co, generator=g) + 0.5).to(DEV), (torch.randn(Co, generator=g) / 3).to(DEV)
+    coef = torch.empty(4, Co, device=DEV)
+    L.call("vae_bn_finalize", L.ptr(ssum), L.ptr(ssq), rows, Co, 1, float(n * H * W), L.ptr(gam), L.ptr(bet), None, None, 0.1, 1e-5, 0,
+           L.ptr(coef[0]), L.ptr(coef[1]), L.ptr(coef[2]), L.ptr(coef[3]), s)
+    ref = torch.full_like(y, float("nan"))
+    L.call("vae_bn_act_fwd", L.ptr(y), L.ptr(coef[0]), L.ptr(coef[1]), L.ptr(ref), n, H, W, Co, 0, 0.0, None, 0, 0, 0, 0, s)
+    out = torch.full_like(y, float("nan"))
+    bits = torch.full((n * H * W, Co // 8), 0xAA, device=DEV, dtype=torch.uint8)
+    L.call("vae_conv3x3_c8_bn_act", L.ptr(x8), L.ptr(wp), L.ptr(bd), L.ptr(coef[0]), L.ptr(coef[1]), L.ptr(out), L.ptr(bits),
+           n, H, W, Co, s)
+    assert torch.equal(out.view(torch.int16), ref.view(torch.int16))
+    want = (ref.float().reshape(n * H * W, Co // 8, 8) > 0).to(torch.int32)
+    packed = (want << torch.arange(8, device=DEV, dtype=torch.int32)).sum(-1).to(torch.uint8)
+    # (an activation that is positive in fp32 and rounds to a positive bf16: the bit and the stored sign agree)
+    assert torch.equal(bits, packed)
+    # without the bits
+    out2 = torch.full_like(y, float("nan"))
+    L.call("vae_conv3x3_c8_bn_act", L.ptr(x8), L.ptr(wp), L.ptr(bd), L.ptr(coef[0]), L.ptr(coef[1]), L.ptr(out2), None, n, H, W, Co, s)
+    assert torch.equal(out2.view(torch.int16), out.view(torch.int16))
+
+
+def test_first_conv_in_two_passes_rejects(L):
+    assert L.call("vae_conv3x3_c8_twice_ok", 1, 6, 6, 64) == 0        # not a power of two
+    assert L.call("vae_conv3x3_c8_twice_ok", 1, 8, 8, 48) == 0        # channels
+    t = torch.zeros(4096, device=DEV)
+    with pytest.raises(RuntimeError, match="not covered"):
+        L.call("vae_conv3x3_c8_stats", L.ptr(t), L.ptr(t), None, L.ptr(t), L.ptr(t), 1, 6, 6, 64, L.current_stream())
+    with pytest.raises(RuntimeError, match="null pointer"):
+        L.call("vae_conv3x3_c8_bn_act", L.ptr(t), L.ptr(t), None, None, None, L.ptr(t), None, 1, 8, 8, 64, L.current_stream())
+
+
 @pytest.mark.parametrize("n,H,W,Ci,Co", [(2, 4, 4, 256, 128), (3, 8, 8, 128, 64), (2, 16, 16, 64, 64), (128, 16, 16, 64, 64),
                                          (512, 8, 8, 128, 64), (700, 4, 4, 256, 128), (400, 16, 16, 64, 64),
                                          (2, 8, 8, 64, 128), (64, 8, 8, 256, 64)])

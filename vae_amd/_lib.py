@@ -40,6 +40,9 @@ SIGNATURES = {
     "vae_gemm_rows_per_block": (c_int, []),
     "vae_gemm_stat_rows": (c_int, [c_long, c_int]),
     "vae_conv3x3_c8_stat_rows": (c_int, [c_int, c_int, c_int, c_int]),
+    "vae_conv3x3_c8_twice_ok": (c_int, [c_int, c_int, c_int, c_int]),
+    "vae_conv3x3_c8_stats": (None, [P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "vae_conv3x3_c8_bn_act": (None, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "vae_convt2x2_stat_rows": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "vae_convt2x2_stat_fold": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "vae_convt2x2_bwd_fused_ok": (c_int, [c_int, c_int, c_int, c_int, c_int]),
@@ -78,6 +81,7 @@ SIGNATURES = {
     "vae_bn_act_bwd_blocks": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "vae_bn_bwd_conv1_scratch_floats": (c_long, [c_int, c_int, c_int]),
     "vae_bn_bwd_conv1": (None, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "vae_bn_bwd_conv1_bits": (None, [P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "vae_colsum_blocks": (c_int, [c_long, c_int]),
     "vae_colsum_bf16": (None, [P, c_long, c_int, P, P, P]),
     "vae_conv1x1_out_fwd": (None, [P, P, P, P, c_int, c_int, c_int, c_int, P]),

@@ -49,6 +49,11 @@ struct Conv1Bwd {
     const float* recon;
     int hw, hwshift;
     float* dl_out;        // optional: the logit gradients dl [pixel][4] (for the fused backward of the layer in front)
+    // bits form (MODE 2): the conv output was never stored.  One bit per element says where the ReLU passed; the tile's
+    // y is rebuilt from the shifted-input tile and the conv's own weight and bias (fp32, parameter layout)
+    const unsigned char* relu_bits;   // [pixel][8]
+    const float* w;                   // [64][Cin][3][3]
+    const float* bias;                // [64]
 };
 
 // swizzles of the 16-byte chunk index: the 8 rows {b..b+3, b+8..b+11} one half of a transposing read touches land on
@@ -82,10 +87,17 @@ __device__ __forceinline__ void c1_wait(bf16x8& f) { asm volatile("s_waitcnt lgk
 // split is good to 2^-17).  Everything the head's backward sums over pixels follows from P2[o][c] = sum_p dl (pos y) and
 // P1[o][c] = sum_p dl pos:  dW[o][c] = scale P2 + shift P1  (a = relu(scale y + shift)),  sum g = sum_o w[o][c] P1,
 // sum g y = sum_o w[o][c] P2  (g = pos * sum_o w[o][c] dl[o]),  db[o] = sum_p dl  (the all-ones row).
+// MODE 2: MODE 0 without the stored conv output (see Conv1Bwd): d = gin where the forward's ReLU bit is set, and the y
+// half of the tile is y = bf16(X W'^T + bias) from the tile's shifted-input rows -- one 16x16x32 matrix instruction per 16
+// pixels x 16 channels (K = the 32 columns of the X tile; W' is the weight in that column order, bf16 as the forward
+// used it).  The forward summed the same products in another order, so a rebuilt y may differ from the forward's in
+// its last bf16 bit; y only enters sums over all pixels here (the ReLU decision itself comes from the bits).
 template <int MODE, int NC>
 __global__ __launch_bounds__(256, 3) void bn_bwd_conv1_kernel(const Conv1Bwd p) {
     constexpr int CIN = NC;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * C1_STAGE];
+    __shared__ __attribute__((aligned(16))) unsigned char wlds[MODE == 2 ? 64 * 64 : 16];
+    __shared__ __attribute__((aligned(16))) float bias_l[MODE == 2 ? 64 : 4];
     typedef __attribute__((address_space(3))) void* lptr_t;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -103,12 +115,21 @@ __global__ __launch_bounds__(256, 3) void bn_bwd_conv1_kernel(const Conv1Bwd p) 
     }
     float sc[8], sh[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { sc[i] = p.scale[c0 + i]; sh[i] = p.shift[c0 + i]; }
+    for (int i = 0; i < 8; ++i) { sc[i] = MODE == 2 ? 0.f : p.scale[c0 + i]; sh[i] = MODE == 2 ? 0.f : p.shift[c0 + i]; }
+    if (MODE == 2) {
+        // W'[co][k], k = tap * Cin + ci (the X tile's column order), zero from 9 * Cin on (column 31 of X is all ones)
+        for (int i = tid; i < 64 * 32; i += 256) {
+            const int co = i >> 5, k = i & 31, tap = k / CIN, ci = k - tap * CIN;
+            ((bf16_t*)wlds)[i] = k < 9 * CIN ? f2bf(p.w[(co * CIN + ci) * 9 + tap]) : (bf16_t)0;
+        }
+        if (tid < 64) bias_l[tid] = p.bias ? p.bias[tid] : 0.f;
+    }
 
     // registers of the tile in flight: two pixels x (gin, y) of this lane's channel group, up to three (pixel, tap) pairs
     // (a second set in flight, so that memory is never idle, measured slower in every form tried: 40-46 vs 32-38 us)
     struct InFlight {
         uint4 g[2], y[2];
+        unsigned bits[2];                   // MODE 2: the ReLU bits of this lane's 8 channels
         uint2 x[3];
         float hr[4], hd[4];                 // MODE 1: recon and drecon of this lane's pixel (lanes 0..63)
     };
@@ -122,9 +143,11 @@ __global__ __launch_bounds__(256, 3) void bn_bwd_conv1_kernel(const Conv1Bwd p) 
         for (int h = 0; h < 2; ++h) {
             const int k = k0 + pl + 32 * h;
             rg[h] = ry[h] = make_uint4(0u, 0u, 0u, 0u);
+            r.bits[h] = 0u;
             if (k < p.npix) {
-                if (MODE == 0) rg[h] = *(const uint4*)(p.gin + (long)k * 64 + c0);
-                ry[h] = *(const uint4*)(p.y + (long)k * 64 + c0);
+                if (MODE != 1) rg[h] = *(const uint4*)(p.gin + (long)k * 64 + c0);
+                if (MODE == 2) r.bits[h] = p.relu_bits[(long)k * 8 + cg];
+                else ry[h] = *(const uint4*)(p.y + (long)k * 64 + c0);
             }
         }
         if (MODE == 1) {
@@ -178,14 +201,16 @@ __global__ __launch_bounds__(256, 3) void bn_bwd_conv1_kernel(const Conv1Bwd p) 
                 for (int e = 0; e < 2; ++e) {
                     const int i = 2 * j + e;
                     const float v = __uint_as_float(e ? (yw[j] & 0xFFFF0000u) : (yw[j] << 16));
-                    if (v * sc[i] + sh[i] > 0.f) keep |= e ? 0xFFFF0000u : 0x0000FFFFu;
+                    const bool pass = MODE == 2 ? ((r.bits[h] >> i) & 1u) != 0u : v * sc[i] + sh[i] > 0.f;
+                    if (pass) keep |= e ? 0xFFFF0000u : 0x0000FFFFu;
                 }
-                dwd[j] = MODE == 0 ? (gw[j] & keep) : (yw[j] & keep);
+                dwd[j] = MODE != 1 ? (gw[j] & keep) : (yw[j] & keep);
                 if (MODE == 1) gw1[j] = 0x3F803F80u & keep;
             }
             const int s = c1_swz_a(row);
             *(uint4*)(abase + row * C1_ROWA + ((cg ^ s) << 4)) = make_uint4(dwd[0], dwd[1], dwd[2], dwd[3]);
-            *(uint4*)(abase + row * C1_ROWA + (((8 + cg) ^ s) << 4)) = MODE == 0 ? ry[h] : make_uint4(gw1[0], gw1[1], gw1[2], gw1[3]);
+            if (MODE != 2)     // (MODE 2: make_y fills the y half once the X tile is complete)
+                *(uint4*)(abase + row * C1_ROWA + (((8 + cg) ^ s) << 4)) = MODE == 0 ? ry[h] : make_uint4(gw1[0], gw1[1], gw1[2], gw1[3]);
         }
         if (MODE == 1) {
             if (tid < C1_BK) {
@@ -256,7 +281,32 @@ __global__ __launch_bounds__(256, 3) void bn_bwd_conv1_kernel(const Conv1Bwd p) 
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[i], cb[j], acc[i][j], 0, 0, 0);
                 if (wave == 0) acc1[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[i], ones, acc1[i], 0, 0, 0);
             }
-            if (MODE == 0) accd = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cb[0], cb[1], accd, 0, 0, 0);
+            if (MODE != 1) accd = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cb[0], cb[1], accd, 0, 0, 0);
+        }
+    };
+
+    // MODE 2: the y half of stage `buf` from its (complete) X tile: wave w makes pixels 16 w .. 16 w + 15
+    bf16x8 wfrag[4];
+    if (MODE == 2) {
+        __syncthreads();                   // wlds, bias_l
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) wfrag[cb] = *(const bf16x8*)(wlds + (16 * cb + (lane & 15)) * 64 + (lane >> 4) * 16);
+    }
+    auto make_y = [&](int buf, int tile) {
+        unsigned char* abase = smem + buf * C1_STAGE;
+        const unsigned char* xbase = abase + C1_A_BYTES;
+        const int row = 16 * wave + (lane & 15), q = lane >> 4;
+        const bf16x8 xb = *(const bf16x8*)(xbase + row * C1_ROWX + ((q ^ c1_swz_x(row)) << 4));
+        const bool valid = tile * C1_BK + row < p.npix;
+        const int sa = c1_swz_a(row);
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            // result register r: channel 16 cb + 4 q + r of pixel `row`
+            const f32x4 yv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfrag[cb], xb, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            const float4 b4 = *(const float4*)(bias_l + 16 * cb + 4 * q);
+            uint2 o = make_uint2(pack2bf(yv[0] + b4.x, yv[1] + b4.y), pack2bf(yv[2] + b4.z, yv[3] + b4.w));
+            if (!valid) o = make_uint2(0u, 0u);
+            *(uint2*)(abase + row * C1_ROWA + (((8 + 2 * cb + (q >> 1)) ^ sa) << 4) + (q & 1) * 8) = o;
         }
     };
 
@@ -268,14 +318,30 @@ __global__ __launch_bounds__(256, 3) void bn_bwd_conv1_kernel(const Conv1Bwd p) 
     __syncthreads();                       // the clear and the ones column are complete
     deposit(r0, 0, tile);
     if (tile + G < p.ntile) fetch(r0, tile + G);
+    if (MODE == 2) {
+        barrier_keep_copies();             // the X tile is complete
+        make_y(0, tile);
+    }
     barrier_keep_copies();
     int buf = 0;
     while (true) {
-        compute(buf);
         const bool more = tile + G < p.ntile;
-        if (more) {
-            deposit(r0, buf ^ 1, tile + G);
-            if (tile + 2 * G < p.ntile) fetch(r0, tile + 2 * G);
+        if (MODE == 2) {
+            // the next tile's d and X first, alone; then its y (which needs the complete X tile) beside this tile's
+            // matrix work: the two have no data in common, so waves in either overlap
+            if (more) {
+                deposit(r0, buf ^ 1, tile + G);
+                if (tile + 2 * G < p.ntile) fetch(r0, tile + 2 * G);
+                barrier_keep_copies();
+                make_y(buf ^ 1, tile + G);
+            }
+            compute(buf);
+        } else {
+            compute(buf);
+            if (more) {
+                deposit(r0, buf ^ 1, tile + G);
+                if (tile + 2 * G < p.ntile) fetch(r0, tile + 2 * G);
+            }
         }
         barrier_keep_copies();             // stage buf is read out, stage buf ^ 1 is written
         if (!more) break;
@@ -297,7 +363,7 @@ __global__ __launch_bounds__(256, 3) void bn_bwd_conv1_kernel(const Conv1Bwd p) 
     }
     // accd[r]: d channel 4 (lane >> 4) + r against y channel (lane & 15) of the wave's block: keep the diagonal
     const int r = (lane & 15) - 4 * (lane >> 4);
-    if (MODE == 0 && r >= 0 && r < 4)
+    if (MODE != 1 && r >= 0 && r < 4)
         out[C1_TROWS * C1_COLS + 16 * wave + (lane & 15)] = r == 0 ? accd[0] : r == 1 ? accd[1] : r == 2 ? accd[2] : accd[3];
 }
 
@@ -450,6 +516,39 @@ extern "C" int vae_bn_bwd_conv1(const void* gin, const void* y, const void* x8, 
     }
     hipLaunchKernelGGL(c1_fold_kernel<0>, dim3(64), dim3(1024), 0, s, scratch, nb, scale, shift, mean, rstd, (const float*)nullptr,
                        1.0 / (double)npix, sums, dW, Cin);
+    VAE_LAUNCH_CHECK("c1_fold_kernel");
+    return 0;
+}
+
+// The same without the stored conv output: `relu_bits` (one bit per element: the forward's ReLU decision, as
+// vae_conv3x3_c8_bn_act leaves it) in place of y, and the conv's own weight / bias, from which each tile's y is rebuilt.
+extern "C" int vae_bn_bwd_conv1_bits(const void* gin, const void* relu_bits, const void* x8, const float* w, const float* bias,
+                                     const float* scale, const float* mean, const float* rstd, float* scratch, float* sums,
+                                     float* dW, int n_img, int H, int W, int Cin, void* stream) {
+    VAE_CHECK(gin && relu_bits && x8 && w && scale && mean && rstd && scratch && sums && dW, "vae_bn_bwd_conv1_bits: null pointer");
+    VAE_CHECK(n_img > 0 && H > 0 && W > 0 && (long)n_img * H * W < (1L << 31) - 64 * C1_MAX_BLOCKS,
+              "vae_bn_bwd_conv1_bits: bad geometry n=%d H=%d W=%d", n_img, H, W);
+    VAE_CHECK(Cin >= 1 && Cin <= 3, "vae_bn_bwd_conv1_bits: Cin=%d out of range (1..3: nine taps of Cin channels must fit 32 columns)", Cin);
+    VAE_CHECK((((uintptr_t)gin | (uintptr_t)scratch) & 15) == 0 && ((uintptr_t)x8 & 7) == 0,
+              "vae_bn_bwd_conv1_bits: gin and scratch must be 16-byte aligned, x8 8-byte aligned");
+    const long npix = (long)n_img * H * W;
+    Conv1Bwd p = {};
+    p.gin = (const bf16_t*)gin; p.relu_bits = (const unsigned char*)relu_bits; p.x8 = (const bf16_t*)x8;
+    p.w = w; p.bias = bias; p.part = scratch;
+    p.npix = (int)npix; p.H = H; p.W = W; p.wshift = c1_shift(W); p.hshift = c1_shift(H); p.Cin = Cin;
+    p.ntile = (int)((npix + C1_BK - 1) / C1_BK);
+    const int nb = c1_blocks(npix);
+    hipStream_t s = (hipStream_t)stream;
+    {
+        // gin read once, a byte of bits per 8 elements, the 8-channel input once
+        ProfScope prof("bn_bwd_conv1_kernel", 0.0, (double)npix * (64 * 2 + 8 + 16), s);
+        if (Cin == 1) hipLaunchKernelGGL((bn_bwd_conv1_kernel<2, 1>), dim3(nb), dim3(256), 0, s, p);
+        else if (Cin == 2) hipLaunchKernelGGL((bn_bwd_conv1_kernel<2, 2>), dim3(nb), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((bn_bwd_conv1_kernel<2, 3>), dim3(nb), dim3(256), 0, s, p);
+        VAE_LAUNCH_CHECK("bn_bwd_conv1_kernel<bits>");
+    }
+    hipLaunchKernelGGL(c1_fold_kernel<0>, dim3(64), dim3(1024), 0, s, scratch, nb, scale, (const float*)nullptr, mean, rstd,
+                       (const float*)nullptr, 1.0 / (double)npix, sums, dW, Cin);
     VAE_LAUNCH_CHECK("c1_fold_kernel");
     return 0;
 }

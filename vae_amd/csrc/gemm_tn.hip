@@ -37,7 +37,8 @@ int conv3_patch_tn_launch(const void* x, const void* w_packed, const float* bias
 bool stream_c8_ok(int n_img, int H, int W, int Cout);
 int stream_c8_rows(int n_img, int H, int W);
 int stream_c8_launch(const void* x8, const void* w_packed, const float* bias, void* y, float* stat_sum, float* stat_sq,
-                     int n_img, int H, int W, int Cout, double flops, double bytes, hipStream_t s);
+                     const float* scale, const float* shift, void* relu_bits, int n_img, int H, int W, int Cout, double flops,
+                     double bytes, hipStream_t s);
 bool stream_convt_fwd_ok(int n_img, int H, int W, int Cin, int Cout);
 int stream_convt_fwd_rows(int n_img, int H, int W, int Cin, int Cout);
 int stream_convt_fwd_fold(int Cin, int Cout);
@@ -528,8 +529,38 @@ extern "C" int vae_conv3x3_c8_gemm(const void* x8, const void* w_packed, const f
     p.bytes = 2.0 * ((double)p.M * 8 + (double)p.N * p.K + (double)p.M * Cout);
     if (int e = check_common(p, 64, "vae_conv3x3_c8_gemm", (double)p.M * 8)) return e;
     if (stream_c8_ok(n_img, H, W, Cout))
-        return stream_c8_launch(x8, w_packed, bias, y, stat_sum, stat_sq, n_img, H, W, Cout, p.flops, p.bytes, (hipStream_t)stream);
+        return stream_c8_launch(x8, w_packed, bias, y, stat_sum, stat_sq, nullptr, nullptr, nullptr, n_img, H, W, Cout, p.flops,
+                                p.bytes, (hipStream_t)stream);
     return launch_bk64<A_CONV3_C8, E_BF16>(p, (hipStream_t)stream);
+}
+
+// The first conv in two passes: its input is 16 bytes per pixel and its output 128, so convolving twice is cheaper than
+// writing the conv output and reading it back for the BatchNorm.
+extern "C" int vae_conv3x3_c8_twice_ok(int n_img, int H, int W, int Cout) {
+    return n_img > 0 && H > 0 && W > 0 && stream_c8_ok(n_img, H, W, Cout) ? 1 : 0;
+}
+extern "C" int vae_conv3x3_c8_stats(const void* x8, const void* w_packed, const float* bias, float* stat_sum, float* stat_sq,
+                                    int n_img, int H, int W, int Cout, void* stream) {
+    VAE_CHECK(x8 && w_packed && stat_sum && stat_sq, "vae_conv3x3_c8_stats: null pointer");
+    VAE_CHECK(vae_conv3x3_c8_twice_ok(n_img, H, W, Cout), "vae_conv3x3_c8_stats: geometry n=%d %dx%d Cout=%d not covered (vae_conv3x3_c8_twice_ok)",
+              n_img, H, W, Cout);
+    VAE_CHECK(((uintptr_t)x8 & 15) == 0 && ((uintptr_t)w_packed & 15) == 0, "vae_conv3x3_c8_stats: operands must be 16-byte aligned");
+    const double M = (double)n_img * H * W;
+    return stream_c8_launch(x8, w_packed, bias, nullptr, stat_sum, stat_sq, nullptr, nullptr, nullptr, n_img, H, W, Cout,
+                            2.0 * M * Cout * 27.0, 2.0 * (M * 8 + (double)Cout * 128), (hipStream_t)stream);
+}
+extern "C" int vae_conv3x3_c8_bn_act(const void* x8, const void* w_packed, const float* bias, const float* scale,
+                                     const float* shift, void* out, void* relu_bits, int n_img, int H, int W, int Cout,
+                                     void* stream) {
+    VAE_CHECK(x8 && w_packed && scale && shift && out, "vae_conv3x3_c8_bn_act: null pointer");
+    VAE_CHECK(vae_conv3x3_c8_twice_ok(n_img, H, W, Cout), "vae_conv3x3_c8_bn_act: geometry n=%d %dx%d Cout=%d not covered (vae_conv3x3_c8_twice_ok)",
+              n_img, H, W, Cout);
+    VAE_CHECK(((uintptr_t)x8 & 15) == 0 && ((uintptr_t)w_packed & 15) == 0 && ((uintptr_t)out & 15) == 0,
+              "vae_conv3x3_c8_bn_act: operands must be 16-byte aligned");
+    const double M = (double)n_img * H * W;
+    return stream_c8_launch(x8, w_packed, bias, out, nullptr, nullptr, scale, shift, relu_bits, n_img, H, W, Cout,
+                            2.0 * M * Cout * 27.0, 2.0 * (M * 8 + (double)Cout * 128 + M * Cout) + (relu_bits ? M * Cout / 8 : 0.0),
+                            (hipStream_t)stream);
 }
 
 extern "C" int vae_convt2x2_fwd_gemm(const void* x, const void* w_packed, const float* bias, void* y,

@@ -15,7 +15,7 @@
 
 #include "model_layout.h"
 
-namespace vae { extern int g_conv1_bwd_mode; extern int g_pool_ymax_mode; extern int g_convt_bwd_mode; extern int g_head_sums_mode; int g_fold_defer_mode = 0; int g_slab_reparam_mode = 0; int g_wgrad_batch_mode = 0; }
+namespace vae { extern int g_conv1_bwd_mode; extern int g_pool_ymax_mode; extern int g_convt_bwd_mode; extern int g_head_sums_mode; int g_fold_defer_mode = 0; int g_slab_reparam_mode = 0; int g_wgrad_batch_mode = 0; int g_conv1_twice_mode = 0; }
 
 namespace {
 using namespace vae_model;
@@ -62,6 +62,7 @@ struct WsLayout {
     long bnpart, headpart, headsums, slab, dz, dmu, dlv, dcat, dpre, colp;
     long slab_floats;
     long g[3];              // gradient ping-pong buffers (three: a weight-gradient kernel may still read one)
+    long relu_bits;         // first conv in two passes: one bit per element of its activation, "the ReLU passed"
     long route[3];          // pooled blocks: one byte per pooled element, which window element won and whether it is live
     long ymax[3];           // pooled blocks: the conv output at each window's maximum (bf16), for the backward sums
     long dyb[4], dya[4];    // gradients of the two conv outputs of each encoder block: kept until the stage's ONE weight-gradient launch
@@ -71,6 +72,12 @@ struct WsLayout {
 
 // the first conv's BatchNorm backward and weight gradient as one kernel (it holds nine taps x Cin columns in 32)
 static bool conv1_one_pass(const Dims& d) { return vae::g_conv1_bwd_mode == 0 && d.Cin <= 3; }
+// The first conv's output (128 bytes per pixel made from 16) is never stored: the forward convolves twice -- statistics,
+// then BatchNorm + ReLU in the epilogue, leaving the activation and one ReLU bit per element -- and the one-pass
+// backward rebuilds y per tile.  Needs that backward form (the separate passes read the stored tensor).
+static bool conv1_twice(const Dims& d) {
+    return vae::g_conv1_twice_mode == 0 && conv1_one_pass(d) && vae_conv3x3_c8_twice_ok(d.N, d.S, d.S, ENC_C[0]);
+}
 
 long enc_elems(const Dims& d, int b) { const long h = d.S >> b; return (long)d.N * h * h * ENC_C[b]; }
 
@@ -83,6 +90,7 @@ void make_ws_layout(const Dims& d, WsLayout* w) {
     auto put = [&](long bytes) { long r = o; o += align_up(bytes, 256); return r; };
     const long npix = (long)d.N * d.S * d.S;
     w->x8 = put(npix * 8 * 2);
+    w->relu_bits = put(npix * (ENC_C[0] / 8));
     for (int b = 0; b < 4; ++b) {
         const long e = enc_elems(d, b);
         w->ya[b] = put(e * 2); w->aa[b] = put(e * 2); w->yb[b] = put(e * 2);
@@ -351,14 +359,22 @@ static int encoder_forward(const Ctx& c, const float* x, const void* const* mask
         const long M = (long)d.N * H * H;
         const int rows_a = b == 0 ? vae_conv3x3_c8_stat_rows(d.N, H, H, C) : vae_conv3x3_stat_rows(d.N, H, H, ENC_C[b - 1], C);
         const int rows = vae_conv3x3_stat_rows(d.N, H, H, C, C);
-        if (b == 0)
+        const bool twice = b == 0 && conv1_twice(d);
+        if (twice) {
+            if (train) TRY(vae_conv3x3_c8_stats(in, c.pk_at(c.pk.c1a), c.P(1), ss, sq, d.N, H, H, C, c.stream));
+        } else if (b == 0) {
             TRY(vae_conv3x3_c8_gemm(in, c.pk_at(c.pk.c1a), c.P(1), c.at(w.ya[0]), ss, sq, d.N, H, H, C, c.stream));
-        else
+        } else {
             TRY(vae_conv3x3_gemm(in, c.pk_at(c.pk.conv_f[2 * b - 1]), c.P(8 * b + 1), c.at(w.ya[b]), ss, sq, d.N, H, H,
                                  ENC_C[b - 1], C, c.stream));
+        }
         TRY(bn_finalize(c, 2 * b, 8 * b + 2, rows_a, 1, (double)M));
-        TRY(vae_bn_act_fwd(c.at(w.ya[b]), c.coef(2 * b, 0), c.coef(2 * b, 1), c.at(w.aa[b]), d.N, H, H, C, 0, 0.0, nullptr,
-                           0, 0, 0, 0, c.stream));
+        if (twice)
+            TRY(vae_conv3x3_c8_bn_act(in, c.pk_at(c.pk.c1a), c.P(1), c.coef(0, 0), c.coef(0, 1), c.at(w.aa[0]),
+                                      train ? c.at(w.relu_bits) : nullptr, d.N, H, H, C, c.stream));
+        else
+            TRY(vae_bn_act_fwd(c.at(w.ya[b]), c.coef(2 * b, 0), c.coef(2 * b, 1), c.at(w.aa[b]), d.N, H, H, C, 0, 0.0, nullptr,
+                               0, 0, 0, 0, c.stream));
         TRY(vae_conv3x3_gemm(c.at(w.aa[b]), c.pk_at(c.pk.conv_f[2 * b]), c.P(8 * b + 5), c.at(w.yb[b]), ss, sq, d.N, H, H, C,
                              C, c.stream));
         TRY(bn_finalize(c, 2 * b + 1, 8 * b + 6, rows, 1, (double)M));
@@ -735,8 +751,12 @@ static int backward_block(const Ctx& c, Fork* f, int b, const void* const* masks
         // nothing needs the first conv's input gradient: BatchNorm backward and weight gradient in one pass, no tensor written
         float* scratch = nullptr;
         TRY(slab_take(c, f, vae_bn_bwd_conv1_scratch_floats(d.N, H, H), &scratch));
-        TRY(vae_bn_bwd_conv1(c.at(w.g[ic]), c.at(w.ya[0]), c.at(w.x8), c.coef(0, 0), c.coef(0, 1), c.coef(0, 2), c.coef(0, 3),
-                             scratch, c.G(2), c.G(0), d.N, H, H, d.Cin, c.stream));
+        if (conv1_twice(d))
+            TRY(vae_bn_bwd_conv1_bits(c.at(w.g[ic]), c.at(w.relu_bits), c.at(w.x8), c.P(0), c.P(1), c.coef(0, 0), c.coef(0, 2),
+                                      c.coef(0, 3), scratch, c.G(2), c.G(0), d.N, H, H, d.Cin, c.stream));
+        else
+            TRY(vae_bn_bwd_conv1(c.at(w.g[ic]), c.at(w.ya[0]), c.at(w.x8), c.coef(0, 0), c.coef(0, 1), c.coef(0, 2), c.coef(0, 3),
+                                 scratch, c.G(2), c.G(0), d.N, H, H, d.Cin, c.stream));
         TRY(side_after_main(f));           // the stage's fold launch follows it: the scratch rows sit in the slab buffer
         return side_mark(f, w_carry);
     }

@@ -26,7 +26,11 @@ namespace vae {
 int g_stream_gemm_mode = 0;    // 0: where it applies and pays, 1: never, 2: wherever it applies (tests, A-B measurements)
 
 enum { SA_PLAIN = 0, SA_C8 = 1 };
-enum { SE_BF16 = 0, SE_CONVT = 1 };
+// SE_STATS: nothing is stored, only the statistics rows leave (the first of two passes over an input that is cheaper
+// to convolve twice than to write out and read back).  SE_BNACT: the second pass -- BatchNorm + ReLU applied to the
+// bf16-rounded result, the activation stored instead of the conv output, and (optionally) one bit per element that
+// says whether the ReLU passed.
+enum { SE_BF16 = 0, SE_CONVT = 1, SE_STATS = 2, SE_BNACT = 3 };
 
 struct StreamGemm {
     const bf16_t* A;
@@ -42,6 +46,9 @@ struct StreamGemm {
     int Co;               // SE_CONVT: channels per tap of the output
     unsigned a_bytes;
     int npairs;           // M / 32
+    const float* scale;   // SE_BNACT: [N] each
+    const float* shift;
+    unsigned char* relu_bits;   // SE_BNACT, optional: [M][N / 8], bit (c & 7) of byte c >> 3 of a pixel = "channel c passed the ReLU"
 };
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4v;
@@ -118,7 +125,17 @@ __global__ __launch_bounds__(256, 3) void stream_gemm_kernel(const StreamGemm p)
     float ssum[16], ssq[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) ssum[e] = ssq[e] = 0.f;
-    const bool want_stats = p.stat_sum != nullptr;
+    const bool want_stats = EPI != SE_BNACT && p.stat_sum != nullptr;
+    // SE_BNACT (one column chunk): scale / shift of this lane's 16 channels, in the order of ssum's slots
+    float bsc[16], bsh[16];
+    if (EPI == SE_BNACT) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int c = n0 + (e >> 3) * 32 + g * 8 + (e & 7);
+            bsc[e] = p.scale[c];
+            bsh[e] = p.shift[c];
+        }
+    }
 
     const int nw = gridDim.x * 4;
     int pair = blockIdx.x * 4 + wave;
@@ -199,6 +216,24 @@ __global__ __launch_bounds__(256, 3) void stream_gemm_kernel(const StreamGemm p)
 #pragma unroll
                         for (int hf = 0; hf < 2; ++hf) {
                             const f32x4 a = acc[hf * 2][i], b = acc[hf * 2 + 1][i];
+                            if (EPI == SE_BNACT) {
+                                // what the separate BatchNorm kernel computes from the stored conv output: the value
+                                // rounded to bf16 first, then mul, add (two roundings), ReLU
+                                float o8[8];
+                                unsigned bits = 0u;
+#pragma unroll
+                                for (int r = 0; r < 8; ++r) {
+                                    const float y = bf2f(f2bf(r < 4 ? a[r] : b[r - 4]));
+                                    const float t = y * bsc[hf * 8 + r] + bsh[hf * 8 + r];
+                                    const bool pos = t > 0.f;
+                                    o8[r] = pos ? t : 0.f;
+                                    bits |= pos ? (1u << r) : 0u;
+                                }
+                                *(uint4*)(p.out + orow + hf * 32 + g * 8) =
+                                    make_uint4(pack2bf(o8[0], o8[1]), pack2bf(o8[2], o8[3]), pack2bf(o8[4], o8[5]), pack2bf(o8[6], o8[7]));
+                                if (p.relu_bits) p.relu_bits[(long)m * (p.N >> 3) + ((nb + hf * 32) >> 3) + g] = (unsigned char)bits;
+                                continue;
+                            }
                             if (want_stats) {
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) {
@@ -206,6 +241,7 @@ __global__ __launch_bounds__(256, 3) void stream_gemm_kernel(const StreamGemm p)
                                     ssum[hf * 8 + 4 + r] += b[r];   ssq[hf * 8 + 4 + r] += b[r] * b[r];
                                 }
                             }
+                            if (EPI == SE_STATS) continue;
                             const uint4 o = make_uint4(pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(b[0], b[1]), pack2bf(b[2], b[3]));
                             // plain stores: the consumer (BatchNorm apply) reads this tensor next, and at these sizes much
                             // of it is still in the memory-side cache (non-temporal stores measured 5-40 % slower here)
@@ -281,13 +317,19 @@ bool stream_c8_ok(int n_img, int H, int W, int Cout) {
 }
 int stream_c8_rows(int n_img, int H, int W) { return stream_grid_x((long)n_img * H * W, 4 * 3 * 1024); }
 
+// y == null: statistics only.  scale / shift set: the activation relu(bf16(conv) * scale + shift) is stored in y's place
+// (and relu_bits, if given); no statistics then.
 int stream_c8_launch(const void* x8, const void* w_packed, const float* bias, void* y, float* stat_sum, float* stat_sq,
-                     int n_img, int H, int W, int Cout, double flops, double bytes, hipStream_t s) {
+                     const float* scale, const float* shift, void* relu_bits, int n_img, int H, int W, int Cout, double flops,
+                     double bytes, hipStream_t s) {
     StreamGemm p = {};
     p.A = (const bf16_t*)x8; p.Wt = (const bf16_t*)w_packed; p.bias = bias; p.out = (bf16_t*)y;
     p.stat_sum = stat_sum; p.stat_sq = stat_sq;
+    p.scale = scale; p.shift = shift; p.relu_bits = (unsigned char*)relu_bits;
     p.M = n_img * H * W; p.N = Cout; p.ldw = 128; p.ldo = Cout; p.H = H; p.W = W;
     p.a_bytes = (unsigned)((long)p.M * 16);
+    if (scale) return stream_launch<SA_C8, SE_BNACT, 3, 1>(p, "stream_gemm_kernel<c8 + bn + relu>", flops, bytes, s);
+    if (!y) return stream_launch<SA_C8, SE_STATS, 3, 1>(p, "stream_gemm_kernel<c8 statistics>", flops, bytes, s);
     return stream_launch<SA_C8, SE_BF16, 3, 1>(p, "stream_gemm_kernel<c8>", flops, bytes, s);
 }
 
