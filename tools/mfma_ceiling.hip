@@ -152,6 +152,74 @@ __global__ __launch_bounds__(512) void loop_kernel(const uint4* __restrict__ src
     if (lane == 0) stamps[blockIdx.x * 8 + wave] = Stamp{c1 - c0, r1 - r0};
 }
 
+// The same loop for other wave tiles: NA x NB fragments of 16 (pixels x channels), 16x16x32 instructions, two k-halves
+// per iteration; PIPE = 0: reads, wait, matrix instructions; 1: the next half's reads ahead of this half's instructions.
+// (NA + NB) reads feed NA * NB instructions: 64 x 32 -> 6 per 8, 64 x 64 -> 8 per 16, 128 x 64 -> 12 per 32.
+template <int NA, int NB, int PIPE>
+__global__ __launch_bounds__(512) void tile_kernel(const uint4* __restrict__ src, float* __restrict__ sink, Stamp* __restrict__ stamps,
+                                                   int iters) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 128 * 128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 2 * 128 * 8; i += blockDim.x) ((uint4*)lds)[i] = src[(blockIdx.x * 2048 + i) & 0xFFFF];
+    __syncthreads();
+    const unsigned base = (unsigned)(size_t)(lptr_t)lds;
+    unsigned a_addr[NA], b_addr[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int row = ((wave & 1) * 64 + i * 16 + (lane & 15)) & 127;
+        a_addr[i] = base + row * 128 + (((lane >> 4) ^ ((row >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int row = ((wave >> 1) * 32 + j * 16 + (lane & 15)) & 127;
+        b_addr[j] = base + 128 * 128 + row * 128 + (((lane >> 4) ^ ((row >> 1) & 7)) << 4);
+    }
+    bf16x8 a[2][NA], b[2][NB];
+    f32x4 acc[NA][NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto fetch = [&](int ks, int buf) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) a[buf][i] = lds_read128(a_addr[i] ^ (ks * 64));
+#pragma unroll
+        for (int j = 0; j < NB; ++j) b[buf][j] = lds_read128(b_addr[j] ^ (ks * 64));
+    };
+    auto mfmas = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[buf][j], a[buf][i], acc[i][j], 0, 0, 0);
+    };
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    if (PIPE) fetch(0, 0);
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            if (PIPE) {
+                lds_wait();
+                fetch(ks ^ 1, ks ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mfmas(ks);
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                fetch(ks, 0);
+                lds_wait();
+                mfmas(0);
+            }
+        }
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) s += acc[i][j][0] + acc[i][j][3];
+    sink[blockIdx.x * blockDim.x + tid] = s;
+    if (lane == 0) stamps[blockIdx.x * 8 + wave] = Stamp{c1 - c0, r1 - r0};
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 template <int MODE, int SHAPE>
@@ -190,6 +258,37 @@ static void run(const char* name, int waves_per_simd, const uint4* src, float* s
            cyc[cyc.size() / 2] / mfma_per_wave / waves_per_simd, last ? "" : ",");
 }
 
+template <int NA, int NB, int PIPE>
+static void run_tile(const char* name, const uint4* src, float* sink, Stamp* stamps, bool last) {
+    const int threads = 512, blocks = 256, iters = 20000 * 16 / (NA * NB);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 300; ++i) hipLaunchKernelGGL((tile_kernel<NA, NB, PIPE>), dim3(blocks), dim3(threads), 0, 0, src, sink, stamps, iters);
+    CK(hipDeviceSynchronize());
+    std::vector<double> ms;
+    for (int rep = 0; rep < 5; ++rep) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL((tile_kernel<NA, NB, PIPE>), dim3(blocks), dim3(threads), 0, 0, src, sink, stamps, iters);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float t; CK(hipEventElapsedTime(&t, e0, e1));
+        ms.push_back(t);
+    }
+    std::sort(ms.begin(), ms.end());
+    std::vector<Stamp> h(blocks * 8);
+    CK(hipMemcpy(h.data(), stamps, h.size() * sizeof(Stamp), hipMemcpyDeviceToHost));
+    std::vector<double> ghz, cyc;
+    for (const Stamp& st : h)
+        if (st.rt) { ghz.push_back((double)st.cyc / (double)st.rt * 0.1); cyc.push_back((double)st.cyc); }
+    std::sort(ghz.begin(), ghz.end()); std::sort(cyc.begin(), cyc.end());
+    const double flop = 2.0 * (NA * 16) * (NB * 16) * 64 * (double)iters * blocks * 8;
+    const double med = ms[ms.size() / 2];
+    printf("  {\"loop\": \"%s\", \"waves_per_simd\": 2, \"tflops\": %.1f, \"frac_of_2500\": %.3f, \"ms\": %.3f, "
+           "\"clock_ghz_in_kernel_median\": %.3f, \"cycles_per_mfma_per_simd\": %.2f}%s\n",
+           name, flop / med / 1e9, flop / med / 1e9 / 2500.0, med, ghz[ghz.size() / 2],
+           cyc[cyc.size() / 2] / (2.0 * NA * NB * iters) / 2, last ? "" : ",");
+}
+
 int main() {
     uint4* src; float* sink; Stamp* stamps;
     CK(hipMalloc(&src, 65536 * sizeof(uint4)));
@@ -221,7 +320,13 @@ int main() {
     run<1, 1>("4 ds_read_b128, wait, 8 mfma, 32x32x16", 1, src, sink, stamps, false);
     run<1, 1>("4 ds_read_b128, wait, 8 mfma, 32x32x16", 2, src, sink, stamps, false);
     run<2, 1>("4 ds_read_b128 one half ahead of 8 mfma, 32x32x16", 1, src, sink, stamps, false);
-    run<2, 1>("4 ds_read_b128 one half ahead of 8 mfma, 32x32x16", 2, src, sink, stamps, true);
+    run<2, 1>("4 ds_read_b128 one half ahead of 8 mfma, 32x32x16", 2, src, sink, stamps, false);
+    run_tile<4, 2, 0>("wave tile 64 x 32: 6 ds_read_b128, wait, 8 mfma", src, sink, stamps, false);
+    run_tile<4, 2, 1>("wave tile 64 x 32: 6 reads one half ahead of 8 mfma", src, sink, stamps, false);
+    run_tile<4, 4, 0>("wave tile 64 x 64: 8 ds_read_b128, wait, 16 mfma", src, sink, stamps, false);
+    run_tile<4, 4, 1>("wave tile 64 x 64: 8 reads one half ahead of 16 mfma", src, sink, stamps, false);
+    run_tile<8, 4, 0>("wave tile 128 x 64: 12 ds_read_b128, wait, 32 mfma", src, sink, stamps, false);
+    run_tile<8, 4, 1>("wave tile 128 x 64: 12 reads one half ahead of 32 mfma", src, sink, stamps, true);
     printf("]}\n");
     return 0;
 }
