@@ -63,7 +63,8 @@ int vae_prof_stop(char* names, int* launches, double* total_ms, double* flops, d
  * always, 2 the streaming kernel wherever its geometry allows (the *_stat_rows functions follow the setting); "wgrad_pc" =
  * 0 the conv3x3 weight gradient with separate copying and computing waves for long K ranges (default), 1 always, 2 never; "conv3_ws64" =
  * 0 the weight-stationary conv3x3 kernel for launches with 64 input channels whose tiles fill the chip (default), 1 never, 2 wherever
- * its geometry allows (16- or 32-wide images, whole 256-pixel tiles), 3 as 0 with a hand-pipelined K loop (faster alone, not in the step on every box); "conv1_bwd" = 0 the whole-model backward runs
+ * its geometry allows (16- or 32-wide images, whole 256-pixel tiles), 3 as 0 with a hand-pipelined K loop (faster alone, not in the step on every box),
+ * 4 as 0 with every wave requesting the next patch at the top of a tile (default: the two waves of a SIMD at opposite ends of the K loop); "conv1_bwd" = 0 the whole-model backward runs
  * the first conv's BatchNorm backward and weight gradient as vae_bn_bwd_conv1 where Cin <= 3 (default), 1 as separate passes;
  * "pool_ymax" = 0 the whole-model passes keep the conv output at each pooling window's maximum for the backward sums (default), 1 they
  * re-read the windows; "head_sums" = 0 vae_head_bwd forms its per-channel sums on the matrix pipe (default), 1 in vector registers; "fold_defer" = 0

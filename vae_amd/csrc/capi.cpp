@@ -91,7 +91,7 @@ extern "C" int vae_set_tuning(const char* key, int value) {
         {"conv3_wide", &vae::g_conv3_wide_mode, 0, 2},        // 0 auto, 1 always the 4-wave kernel, 2 the 8-wave kernel wherever legal
         {"conv3_ksplit", &vae::g_conv3_ksplit_mode, 0, 2},    // 0 auto, 1 never split K inside the workgroup, 2 wherever legal
         {"wgrad_pc", &vae::g_wgrad_pc_mode, 0, 2},            // conv3x3 weight gradient, copying and computing waves separated: 0 by K range, 1 always, 2 never
-        {"conv3_ws64", &vae::g_conv3_ws64_mode, 0, 3},        // weight-stationary conv3x3 for 64 input channels: 0 where its jobs fill the chip, 1 never, 2 wherever legal, 3 as 0, hand-pipelined
+        {"conv3_ws64", &vae::g_conv3_ws64_mode, 0, 4},        // weight-stationary conv3x3 for 64 input channels: 0 where its jobs fill the chip, 1 never, 2 wherever legal, 3 as 0, hand-pipelined
         {"conv1_bwd", &vae::g_conv1_bwd_mode, 0, 1},          // first conv's BatchNorm backward + weight gradient: 0 the one-pass kernel where Cin <= 3, 1 separate passes
         {"pool_ymax", &vae::g_pool_ymax_mode, 0, 1},          // pooled BatchNorm backward sums from the stored window maxima: 0 yes, 1 re-read the windows
         {"head_sums", &vae::g_head_sums_mode, 0, 1},          // the 1x1 head's backward sums: 0 on the matrix pipe, 1 in vector registers

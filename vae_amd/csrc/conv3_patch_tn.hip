@@ -42,6 +42,7 @@ struct PatchTN {
     int PR;               // patch rows
     float inv_per;        // 1 / ((R + 2) * (W + 2))
     unsigned long long* dbg;   // diagnostic builds only: per-workgroup cycle stamps (16 per workgroup), else null
+    int ws64_copy_first;       // conv3_ws64 (A/B aid): every wave requests the next patch at the top of the tile
 };
 
 // pixels per tile: 128, or 256 with the 64-channel tile (the mirror image of 128 pixels x 128 channels: the same
@@ -842,12 +843,17 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv3_ws64_kernel(const Patch
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2048 / NT) : "memory");
         first = false;
         barrier_keep_copies();
-        {   // the next tile's patch goes into the other buffer (last read by the previous epilogue, behind the barrier)
+        // the next tile's patch goes into the other buffer (last read by the previous epilogue, behind the barrier).
+        // A copy holds its wave for 100-200 cycles of issue: the two waves of a SIMD (w and w + 4) request their pieces
+        // at opposite ends of the K loop, so that one's copy issue runs under the other's matrix instructions.
+        auto stage_next = [&]() {
             const int nt = tile + (int)gridDim.x;
             const int nm0 = nt * WS_BM, nh0 = tile_h0(nm0);
 #pragma unroll
             for (int i = 0; i < WS_QP; ++i) stage_piece(i, pbuf ^ 1, nm0, nh0, nt < ntiles);
-        }
+        };
+        const bool copy_first = NW != 8 || wave < 4 || (p.ws64_copy_first != 0);
+        if (copy_first) stage_next();
         f32x4 acc[NF][NJ];
 #pragma unroll
         for (int i = 0; i < NF; ++i)
@@ -900,6 +906,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv3_ws64_kernel(const Patch
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[0][j], xa[0][i], acc[i][j], 0, 0, 0);
             }
         }
+        if (!copy_first) stage_next();
         // ---- epilogue: bias and statistics in registers, the bf16 tile through the patch buffer just consumed
 #pragma unroll
         for (int i = 0; i < NF; ++i)
@@ -977,7 +984,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv3_ws64_kernel(const Patch
 // 0: choose per launch, 1: always the 4-wave kernel, 2: the 8-wave kernel wherever its geometry allows
 int g_conv3_wide_mode = 0;
 // 0: the weight-stationary kernel for 64-input-channel launches that fill the chip, 1: never, 2: wherever its geometry allows,
-// 3: as 0 with the hand-pipelined K loop (PIPE = true; see the kernel)
+// 3: as 0 with the hand-pipelined K loop (PIPE = true; see the kernel), 4: as 0 with every wave requesting the next patch
+// at the top of the tile (the A/B partner of the split copy issue)
 int g_conv3_ws64_mode = 0;
 // 0: choose per launch, 1: never split K inside the workgroup, 2: wherever the chunk count is even
 int g_conv3_ksplit_mode = 0;
@@ -1102,6 +1110,7 @@ int conv3_patch_tn_launch(const void* x, const void* w_packed, const float* bias
     VAE_CHECK(p.PR <= pt_rows(W, plan.bm) && p.rwshift >= 0, "conv3 patch kernel: internal geometry error (PR=%d)", p.PR);
     dim3 grid(plan.gx, plan.gy);
     if (plan.ws64) {
+        p.ws64_copy_first = g_conv3_ws64_mode == 4;
         ProfScope prof("conv3_ws64_kernel", flops, bytes, s);
         if (g_conv3_ws64_mode == 3) {         // the hand-pipelined K loop
             if (W == 16) hipLaunchKernelGGL((conv3_ws64_kernel<16, 8, true>), grid, dim3(512), 0, s, p);
