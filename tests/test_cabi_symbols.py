@@ -206,3 +206,26 @@ def test_batched_weight_gradient_plan(n, size, max_wgs):
         L.call("vae_conv3_wgrad_multi_plan", jobs, len(geo), max_wgs, ns)
     with pytest.raises(RuntimeError, match="out of range"):
         L.call("vae_conv3_wgrad_multi_plan", jobs, 9, max_wgs, ns)
+
+
+def test_batched_weight_gradient_plan_over_many_batches():
+    """every batch size 1..96 and a spread of larger ones, both image sizes, both backward stages: the plan never has an
+    empty K range, never asks for more K ranges than K tiles, and stays within the budget"""
+    import random
+    rnd = random.Random(5)
+    batches = list(range(1, 97)) + [rnd.randrange(97, 5000) for _ in range(60)]
+    for size in (32, 64):
+        stages = ([(size // 8, 256, 256), (size // 8, 256, 256), (size // 4, 256, 256), (size // 4, 128, 256)],
+                  [(size // 2, 128, 128), (size // 2, 64, 128), (size, 64, 64)])
+        for n in batches:
+            for geo in stages:
+                jobs = (L.WgradJob * len(geo))()
+                for q, (H, Ci, Co) in zip(jobs, geo):
+                    q.n_img, q.H, q.W, q.Cin, q.Cout = n, H, H, Ci, Co
+                ns = (ctypes.c_int * len(geo))()
+                L.call("vae_conv3_wgrad_multi_plan", jobs, len(geo), 256, ns)
+                tiles = [(Ci // 64) * (Co // 64) for _, Ci, Co in geo]
+                ktiles = [-(-n * H * H // 64) for H, _, _ in geo]
+                assert all(1 <= s <= k for s, k in zip(ns, ktiles)), (size, n, list(ns))
+                assert all((s - 1) * -(-k // s) < k for s, k in zip(ns, ktiles)), (size, n, list(ns))
+                assert sum(t * s for t, s in zip(tiles, ns)) <= max(256, sum(tiles)), (size, n, list(ns))

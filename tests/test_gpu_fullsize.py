@@ -182,6 +182,48 @@ def test_full_size_properties(N, L, S):
     assert all(torch.isfinite(torch.tensor(losses))) and max(losses[-5:]) < losses[0]
 
 
+@pytest.mark.parametrize("N,S", [(1, 32), (2, 32), (3, 32), (5, 32), (7, 32), (12, 32), (33, 32), (100, 32), (1, 64), (3, 64), (17, 64)])
+def test_launch_forms_agree_at_any_batch(N, S):
+    """the same pass with the conv3x3 weight gradients of a stage in one launch or one launch per layer, and with the
+    first conv in two passes or stored: same loss inputs, gradients equal to the order of their sums (1e-4 per tensor);
+    covers the K-split planner and the slab carving at batches from 1 up (every workgroup budget from 'one K tile' on)"""
+    from vae_amd import _lib
+    from vae_amd.optim import FlatAdamW
+    from vae_amd.train import Config, FusedStep
+    m = _model(64, S)
+    m.train()
+    x = torch.rand(N, 3, S, S, device=DEV, generator=torch.Generator(device=DEV).manual_seed(N + S))
+    fs = FusedStep(m, FlatAdamW(m, lr=1e-4), Config(kl_weight=1.0, percep_weight=0.0, recon_loss="l1", lr=1e-4), None)
+
+    def grads(staged=False):
+        m.rng_step = 5
+        recon, mu_, lv_, state = m.forward_raw(x, None, None)
+        d_recon, partial, out3, grid = fs._buffers(recon, x.device)
+        _lib.call("vae_recon_loss_fwd_bwd", recon.data_ptr(), x.data_ptr(), d_recon.data_ptr(), partial.data_ptr(),
+                  recon.numel(), fs.kind, 1.0 / N, _lib.current_stream())
+        m.flat_grads.zero_()
+        for stage in ((0, 1, 2) if staged else (-1,)):
+            m.backward_raw(state, d_recon, None, None, 1.0 / N, stage)
+        m._release_workspace(state["batch"], state["ws"])
+        torch.cuda.synchronize()
+        return [g.clone() for g in m.grad_views()], recon.clone()
+
+    base, r0 = grads()
+    staged, _ = grads(staged=True)
+    assert all(torch.equal(a, b) for a, b in zip(base, staged))
+    names = [k for k, _ in m.named_parameters()]
+    for key in (b"wgrad_batch", b"conv1_twice"):
+        _lib.call("vae_set_tuning", key, 1)
+        try:
+            other, r1 = grads()
+        finally:
+            _lib.call("vae_set_tuning", key, 0)
+        assert torch.equal(r0, r1), key                               # the forward output does not depend on either
+        for k, a, b in zip(names, base, other):
+            assert torch.isfinite(a).all() and torch.isfinite(b).all(), k
+            assert rel_l2(a.cpu(), b.cpu()) <= 1e-4, (key, k, rel_l2(a.cpu(), b.cpu()))
+
+
 @pytest.mark.parametrize("N,L,S,p", [(6, 64, 24, 0.1), (3, 64, 40, 0.0), (130, 64, 16, 0.2), (1, 128, 32, 0.1), (2, 128, 128, 0.1)])
 def test_ragged_shapes_against_the_oracle(N, L, S, p):
     """image sizes that are not powers of two (the generic kernels), odd batches, a batch of one: train-mode forward,
