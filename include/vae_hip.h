@@ -144,7 +144,9 @@ int vae_reparam_kl_bwd_slabs(const float* dz, int nsplit, const float* mu, const
                              unsigned rank, void* stream);
 /* raw streams, for RNG parity checks.  mode 0: uint32 words, 1: fp32 normals, 2: uint8 keep-mask
  * with drop probability p_drop (16-bit draws, 8 elements per Philox block; kept iff draw >=
- * vae_dropout_threshold(p) = ceil(p * 2^16)).  (torch.randn_like vae.py:110 / nn.Dropout vae.py:137) */
+ * vae_dropout_threshold(p) = ceil(p * 2^16)); 3: no stream but the normal generator's logarithm over its whole
+ * domain, out[i] = ln((i + 1) 2^-24) for i < n <= 2^24 (the uniform of 24-bit draw i), so that it can be compared with a
+ * host restatement value by value.  (torch.randn_like vae.py:110 / nn.Dropout vae.py:137) */
 int vae_philox_fill(void* out, long n, int mode, double p_drop, unsigned long long seed,
                     unsigned step, unsigned stream_id, unsigned rank, void* stream);
 unsigned vae_dropout_threshold(double p_drop);

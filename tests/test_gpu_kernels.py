@@ -57,6 +57,19 @@ def test_philox_streams_bit_exact(L, n):
     assert L.call("vae_dropout_threshold", 0.1) == O.dropout_threshold(0.1)
 
 
+def test_generator_logarithm_bit_exact_over_its_whole_domain(L):
+    """the normal generator takes ln(u) of the 2^24 uniforms (k + 1) 2^-24 and of nothing else: every one of them
+    against the host restatement (numpy's correctly rounded fp32 division inside), bit for bit -- the kernel's
+    division is a reciprocal + one correction, which is only as good as this table says"""
+    n = 1 << 24
+    out = torch.empty(n, dtype=torch.float32, device=DEV)
+    L.call("vae_philox_fill", L.ptr(out), n, 3, 0.0, 0, 0, 0, 0, L.current_stream())
+    u = ((np.arange(n, dtype=np.float32) + np.float32(1.0)) * np.float32(2.0 ** -24)).astype(np.float32)
+    ref = O._log_f32(u)
+    got = out.cpu().numpy()
+    assert (got.view(np.uint32) == ref.view(np.uint32)).all(), int((got.view(np.uint32) != ref.view(np.uint32)).sum())
+
+
 # ------------------------------------------------------------------ loss
 @pytest.mark.parametrize("kind", list(range(5)))
 @pytest.mark.parametrize("n", [4 * 3 * 32 * 32, 1027])

@@ -123,7 +123,14 @@ __device__ __forceinline__ float log_f32_exact(float u) {
     float m = __uint_as_float((bits & 0x007FFFFFu) | 0x3F800000u);
     if (m > 1.41421356237309504880f) { m = __fmul_rn(m, 0.5f); e += 1; }
     const float f = __fadd_rn(m, -1.0f);
-    const float s = __fdiv_rn(f, __fadd_rn(2.0f, f));
+    // s = f / (2 + f), correctly rounded: reciprocal, quotient, one correction -- the core of the IEEE division sequence
+    // without its scaling and special-case steps (f is in [-0.30, 0.42], the divisor in [1.70, 2.42]).  The generator
+    // calls this with the 2^24 values (k + 1) 2^-24 only, and over ALL of them it returns the bits of the full division
+    // (vae_philox_fill mode 3 tabulates them; tests/test_gpu_kernels.py compares the table with numpy's division).
+    const float den = __fadd_rn(2.0f, f);
+    const float rc = __builtin_amdgcn_rcpf(den);
+    const float q0 = __fmul_rn(f, rc);
+    const float s = __builtin_fmaf(__builtin_fmaf(-den, q0, f), rc, q0);
     const float s2 = __fmul_rn(s, s);
     float p = (float)(2.0 / 11);
     p = __fadd_rn(__fmul_rn(p, s2), (float)(2.0 / 9));

@@ -94,12 +94,13 @@ __global__ __launch_bounds__(256) void reparam_kl_fwd_kernel(
         } else {
             philox_normal4(key, (uint32_t)b, e);
         }
-        // one exponential per element: exp(lv) = sd * sd (two roundings instead of one, ~1e-7 relative); the
-        // accurate expf is ~12 vector instructions and this kernel is ALU-bound beside the Philox stream
+        // one exponential per element: exp(lv) = sd * sd (two roundings instead of one, ~1e-7 relative), and that one
+        // from the hardware's exp2 (__expf: a multiply and v_exp_f32, ~2e-7 relative; the accurate expf is ~12 vector
+        // instructions and this kernel is ALU-bound beside the Philox stream).  Results are compared at 1e-5.
         float t[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float sd = expf(0.5f * lv[j]);
+            const float sd = __expf(0.5f * lv[j]);
             z[j] = m[j] + sd * e[j];
             t[j] = 1.f + lv[j] - m[j] * m[j] - sd * sd;
         }
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(256) void reparam_kl_bwd_kernel(
             float g = 0.f;
             if (dz) g = nsplit > 0 ? gsum[j] : dz[i];
             const float lv = logvar[i];
-            const float sd = expf(0.5f * lv);
+            const float sd = __expf(0.5f * lv);
             float gm = g + kl_scale * mu[i];
             float gl = g * e[j] * 0.5f * sd + kl_scale * 0.5f * (sd * sd - 1.f);
             if (dmu_ext) gm += dmu_ext[i];
@@ -203,6 +204,10 @@ __global__ __launch_bounds__(256) void philox_fill_kernel(void* __restrict__ out
             float z[4];
             philox_normal4(key, (uint32_t)b, z);
             for (int j = 0; j < 4 && i0 + j < n; ++j) ((float*)out)[i0 + j] = z[j];
+        } else if (MODE == 3) {
+            // the generator's logarithm over its whole domain: element i = ln((i + 1) 2^-24), the uniform of 24-bit draw i
+            for (int j = 0; j < 4 && i0 + j < n; ++j)
+                ((float*)out)[i0 + j] = log_f32_exact(__fmul_rn(__fadd_rn((float)(uint32_t)(i0 + j), 1.0f), 5.9604644775390625e-08f));
         } else {
             uint32_t w[4];
             philox_block(key, (uint32_t)b, w);
@@ -293,7 +298,8 @@ extern "C" int vae_reparam_kl_bwd_slabs(const float* dz, int nsplit, const float
 extern "C" int vae_philox_fill(void* out, long n, int mode, double p_drop, unsigned long long seed,
                                unsigned step, unsigned stream_id, unsigned rank, void* stream) {
     VAE_CHECK(out && n > 0, "vae_philox_fill: bad arguments");
-    VAE_CHECK(mode >= 0 && mode <= 2, "vae_philox_fill: unknown mode %d", mode);
+    VAE_CHECK(mode >= 0 && mode <= 3, "vae_philox_fill: unknown mode %d", mode);
+    VAE_CHECK(mode != 3 || n <= (1L << 24), "vae_philox_fill: mode 3 tabulates at most 2^24 values");
     PhiloxKey key;
     key.seed_lo = (uint32_t)seed; key.seed_hi = (uint32_t)(seed >> 32);
     key.step = step; key.stream = stream_id; key.rank = rank;
@@ -302,6 +308,7 @@ extern "C" int vae_philox_fill(void* out, long n, int mode, double p_drop, unsig
     hipStream_t s = (hipStream_t)stream;
     if (mode == 0) hipLaunchKernelGGL(philox_fill_kernel<0>, dim3(grid), dim3(256), 0, s, out, n, key, thr);
     else if (mode == 1) hipLaunchKernelGGL(philox_fill_kernel<1>, dim3(grid), dim3(256), 0, s, out, n, key, thr);
+    else if (mode == 3) hipLaunchKernelGGL(philox_fill_kernel<3>, dim3(grid), dim3(256), 0, s, out, n, key, thr);
     else hipLaunchKernelGGL(philox_fill_kernel<2>, dim3(grid), dim3(256), 0, s, out, n, key, thr);
     VAE_LAUNCH_CHECK("philox_fill_kernel");
     return 0;
