@@ -345,20 +345,29 @@ __device__ __forceinline__ void wgrad_pc_body(const PatchP& p, int n0, int m0, i
     const int kt_beg = split * p.kps, kt_end = min(kt_beg + p.kps, p.ktiles);
     const int ntile = kt_end - kt_beg;
 
-    int q_st[QI];
+    // A copy holds its wave -- and the issue port of its SIMD, which the computing wave there needs for its matrix
+    // instructions -- for as long as its address arithmetic takes.  Everything that does not depend on the K tile is
+    // worked out here, once per lane and copy slot, so that a copy costs two adds, two compares and a select (no
+    // multiply, no branch).  q_off: byte offset of the lane's 16 bytes for K tile 0; q_pix: pixel offset inside the tile
+    // (a padding row gets one that is out of range for every tile); q_r: image-row offset.
+    int q_off[QI], q_pix[QI], q_r[QI];
     const int ninstr = (p.PR + 7) >> 3;
+    const unsigned rowb = (unsigned)p.Ci * 2;
 #pragma unroll
     for (int i = 0; i < QI; ++i) {
         const int prow = (wave + 4 * i) * 8 + (lane >> 3);
         const int per = (p.R + 2) * W2;
         const int g = prow / per, rem = prow - g * per;
         const int rr = rem / W2, xx = rem - rr * W2;
-        int st = ((lane & 7) ^ swz128(xx)) << 16;
-        if (prow < p.PR && xx >= 1 && xx <= W) st |= ((g * p.R + (rr - 1)) * W + (xx - 1) + 128) | (rr << 8) | (1 << 24);
-        q_st[i] = st;
+        const bool pixel = prow < p.PR && xx >= 1 && xx <= W;
+        const int pix = (g * p.R + (rr - 1)) * W + (xx - 1);
+        q_pix[i] = pixel ? pix : (int)0xC0000000;          // k0 + this is never in [0, Ktot)
+        q_r[i] = rr - 1;
+        q_off[i] = pix * (int)rowb + n0 * 2 + (((lane & 7) ^ swz128(xx)) << 4);
     }
     const int p_row0 = wave * 8 + (lane >> 3);
-    const int p_ch0 = (lane & 7) ^ swz128(p_row0);
+    const unsigned prow_b = (unsigned)p.Co * 2;
+    const int p_off0 = p_row0 * (int)prow_b + m0 * 2 + (((lane & 7) ^ swz128(p_row0)) << 4);
     constexpr unsigned OOB = 0xFFFFFFFFu;
     const __amdgpu_buffer_rsrc_t p_rsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)p.P, 0, (int)((unsigned)p.Ktot * (unsigned)p.Co * 2u), 0x00020000);
@@ -370,28 +379,22 @@ __device__ __forceinline__ void wgrad_pc_body(const PatchP& p, int n0, int m0, i
         unsigned char* pbase = smem + buf * STAGE;
         unsigned char* qbase = pbase + P_BYTES;
         const int k0 = kt * 64;
-        const int ktot = kt < kt_end ? p.Ktot : 0;      // wave-uniform
+        const unsigned ktot = kt < kt_end ? (unsigned)p.Ktot : 0u;      // wave-uniform
         {
-            int ra = p_row0, ca = p_ch0;
-            asm volatile("" : "+v"(ra), "+v"(ca));
-            const int ka = k0 + ra, kb = ka + 32;       // rows 32 apart agree in both swizzle bits
-            const unsigned prow = (unsigned)p.Co * 2;
-            const unsigned oa = ka < ktot ? (unsigned)ka * prow + (unsigned)(m0 * 2 + ca * 16) : OOB;
-            const unsigned ob = kb < ktot ? (unsigned)kb * prow + (unsigned)(m0 * 2 + ca * 16) : OOB;
+            const unsigned base = (unsigned)k0 * prow_b;                // scalar
+            const int ka = k0 + p_row0;                                 // rows 32 apart agree in both swizzle bits
+            const unsigned oa = (unsigned)ka < ktot ? base + (unsigned)p_off0 : OOB;
+            const unsigned ob = (unsigned)(ka + 32) < ktot ? base + 32u * prow_b + (unsigned)p_off0 : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(p_rsrc, (lptr_t)(pbase + wave * 1024), 16, (int)oa, 0, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(p_rsrc, (lptr_t)(pbase + (wave + 4) * 1024), 16, (int)ob, 0, 0, 0);
         }
-        const unsigned rowb = (unsigned)p.Ci * 2;
+        const unsigned base = (unsigned)k0 * rowb;                      // scalar
         const int h0 = p.G == 1 ? ((k0 >> p.wshift) & (p.H - 1)) : 0;
 #pragma unroll
         for (int i = 0; i < QI; ++i) {
             if (wave + 4 * i < ninstr) {     // wave-uniform
-                int st = q_st[i];
-                asm volatile("" : "+v"(st));
-                const int k = k0 + (st & 255) - 128, r = ((st >> 8) & 255) - 1;
-                unsigned off = OOB;
-                if ((st >> 24) && (unsigned)(h0 + r) < (unsigned)p.H && (unsigned)k < (unsigned)ktot)
-                    off = (unsigned)k * rowb + (unsigned)(n0 * 2 + ((st >> 12) & 0x70));
+                const bool ok = ((unsigned)(h0 + q_r[i]) < (unsigned)p.H) & ((unsigned)(k0 + q_pix[i]) < ktot);
+                const unsigned off = ok ? base + (unsigned)q_off[i] : OOB;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(q_rsrc, (lptr_t)(qbase + (wave + 4 * i) * 1024), 16, (int)off, 0, 0, 0);
             }
         }
