@@ -9,6 +9,7 @@
 //             channel, pass 2 writes dy = scale * (g - mean(g) - xhat * mean(g*xhat)).
 #include "common.h"
 #include "act.h"
+#include <type_traits>
 #include "prof.h"
 #include "../../include/vae_hip.h"
 
@@ -207,25 +208,64 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16_t* __restric
             int wo, ho;
             long img;
             split_pooled(g, pos, wo, ho, img);
-            uint32_t arg[8];
-            float ys[8];                       // the conv output at the window's maximum
+            // The scan keeps, per channel, the running maximum and ONE word beside it: the bits of the conv output there
+            // (bf16, so the low half of the word is free) with the window position in bits 0-1.  Keep flags become a
+            // multiplier (1 / keep or 0) instead of a lane mask: no mask registers, one select per element.
+            uint32_t ya[8];
+            auto scan = [&](auto drop) {
+                constexpr bool DROP = decltype(drop)::value;
+                // the window's four loads go out together, ahead of the generator's arithmetic
+                const long e00 = ((img * g.H + 2 * ho) * g.W + 2 * wo) * g.C + c0;
+                u32x4s uu[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const long pix = (img * g.H + 2 * ho + (k >> 1)) * g.W + 2 * wo + (k & 1);
-                float v[8], a[8];
-                load8s(y + pix * g.C + c0, v);
-                act8(v, sc, sh, d, pix * g.C + c0, a, ps, kp);
+                for (int k = 0; k < 4; ++k)
+                    uu[k] = __builtin_nontemporal_load((const u32x4s*)(y + e00 + ((k >> 1) * g.W + (k & 1)) * g.C));
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    if (k == 0) { o[i] = a[i]; arg[i] = 0; ys[i] = v[i]; }
-                    else if (a[i] > o[i]) { o[i] = a[i]; arg[i] = k; ys[i] = v[i]; }       // strict >: the first maximum wins, as in MaxPool2d
+                for (int k = 0; k < 4; ++k) {
+                    const long e0 = e00 + ((k >> 1) * g.W + (k & 1)) * g.C;
+                    const u32x4s u = uu[k];
+                    float km[8];
+                    if (DROP) {
+                        if (d.mask) {
+                            const uint2 m = *(const uint2*)(d.mask + e0);
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) km[i] = (((i < 4 ? m.x : m.y) >> (8 * (i & 3))) & 0xFFu) ? d.inv_keep : 0.f;
+                        } else {
+                            uint32_t w[4];
+                            philox_block(d.key, (uint32_t)(e0 >> 3), w);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                km[2 * i] = (w[i] & 0xFFFFu) >= d.thr ? d.inv_keep : 0.f;
+                                km[2 * i + 1] = (w[i] >> 16) >= d.thr ? d.inv_keep : 0.f;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const uint32_t vb = (i & 1) ? (u[i >> 1] & 0xFFFF0000u) : (u[i >> 1] << 16);
+                        const float a = __uint_as_float(vb) * sc[i] + sh[i];
+                        float r = a > 0.f ? a : 0.f;
+                        if (DROP) r *= km[i];
+                        if (k == 0) { o[i] = r; ya[i] = vb; }
+                        else {
+                            const bool c = r > o[i];        // strict >: the first maximum wins, as in MaxPool2d
+                            o[i] = c ? r : o[i];
+                            ya[i] = c ? (vb | (uint32_t)k) : ya[i];
+                        }
+                    }
                 }
+            };
+            if (d.enabled) scan(std::true_type{});
+            else scan(std::false_type{});
+            if (ymax) {         // exact: the values are bf16 already
+                const u32x4s q = {(ya[0] >> 16) | (ya[1] & 0xFFFF0000u), (ya[2] >> 16) | (ya[3] & 0xFFFF0000u),
+                                  (ya[4] >> 16) | (ya[5] & 0xFFFF0000u), (ya[6] >> 16) | (ya[7] & 0xFFFF0000u)};
+                __builtin_nontemporal_store(q, (u32x4s*)(ymax + (long)pos * g.C + c0));
             }
-            if (ymax) store8s(ymax + (long)pos * g.C + c0, ys);      // exact: the values are bf16 already
             if (route) {
                 uint32_t r[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) r[i] = arg[i] | (o[i] > 0.f ? 4u : 0u);
+                for (int i = 0; i < 8; ++i) r[i] = (ya[i] & 3u) | (o[i] > 0.f ? 4u : 0u);
                 *(uint2*)(route + (long)pos * g.C + c0) = make_uint2(r[0] | (r[1] << 8) | (r[2] << 16) | (r[3] << 24),
                                                                       r[4] | (r[5] << 8) | (r[6] << 16) | (r[7] << 24));
             }
