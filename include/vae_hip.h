@@ -75,7 +75,8 @@ int vae_prof_stop(char* names, int* launches, double* total_ms, double* flops, d
  * vae_model_backward computes the conv3x3 weight gradients of a backward stage in ONE launch (vae_conv3_wgrad_patch_multi: a seventh
  * of the split-K slab traffic; default), 1 one launch per layer; "conv1_twice" = 0 the whole-model passes
  * convolve the first layer twice and never store its output (vae_conv3x3_c8_stats / _bn_act / vae_bn_bwd_conv1_bits; default, needs
- * "conv1_bwd" = 0), 1 they store it; "wgrad_ablate" = 0..7, only in a library built with
+ * "conv1_bwd" = 0), 1 they store it; "reduce_direct" = 1 split-K slab folds of at most 8 slabs run one thread per 16-byte column with no
+ * barrier (default), 0 they take the split-group form of the longer folds; "wgrad_ablate" = 0..7, only in a library built with
  * -DVAE_ABLATE (a no-op otherwise): vae_conv3_wgrad_patch on 32-wide images runs without its matrix instructions (bit 0),
  * its copies (bit 1), its fragment reads (bit 2) -- wrong results, for timing what bounds the kernel.  Unknown keys and
  * values outside a key's range are rejected.  Not thread-safe: set it while nothing is being launched, and never

@@ -70,6 +70,7 @@ extern int g_fold_defer_mode;
 extern int g_slab_reparam_mode;
 extern int g_convt_bwd_mode;
 extern int g_wgrad_batch_mode;
+extern int g_reduce_direct_mode;
 extern int g_conv1_twice_mode;
 extern int g_wgrad_ablate;
 extern unsigned long long* g_conv3_dbg;
@@ -100,6 +101,7 @@ extern "C" int vae_set_tuning(const char* key, int value) {
         {"convt_bwd", &vae::g_convt_bwd_mode, 0, 2},          // 64 -> 64 ConvTranspose backward: 0 one kernel that also makes the head's gradient, 1 separate kernels, 2 one kernel reading the stored gradient
         {"wgrad_ablate", &vae::g_wgrad_ablate, 0, 7},         // diagnostic builds (-DVAE_ABLATE) only: bit 0 no matrix instructions, 1 no copies, 2 no fragment reads (32-wide images)
         {"conv1_twice", &vae::g_conv1_twice_mode, 0, 1},      // first conv: 0 convolved twice, its output never stored (needs conv1_bwd = 0), 1 stored
+        {"reduce_direct", &vae::g_reduce_direct_mode, 0, 1},  // slab folds of at most 8 slabs: 1 one thread per float4 column, no barrier (default), 0 the split-group form
         {"wgrad_batch", &vae::g_wgrad_batch_mode, 0, 1},      // conv3x3 weight gradients of a backward stage: 0 ONE launch for all of them, 1 one launch per layer
         {"stream_gemm", &vae::g_stream_gemm_mode, 0, 2},      // 0 the streaming GEMM where it pays, 1 never (tiled GEMM), 2 wherever legal
     };

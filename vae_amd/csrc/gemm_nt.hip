@@ -323,13 +323,52 @@ __device__ __forceinline__ void reduce_slabs_scatter_body(const float* __restric
     }
 }
 
-static inline bool reduce_wide_groups(int nsplit) { return nsplit >= 64; }
+// Few slabs (<= 8) of many elements: no split groups, no LDS, no barrier.  A thread owns one float4 column, has every
+// slab's value of it in flight at once, adds them as a fixed tree and scatters the four sums; the split-group form
+// leaves most of its threads with one load (or none) per barrier-bounded round there.
+__device__ __forceinline__ void reduce_slabs_direct_body(const float* __restrict__ slab, int nsplit, long slab_stride,
+                                                         float* __restrict__ out, long n, const IndexMap& mp,
+                                                         const Limits& lim, int accumulate) {
+    const long n4 = n >> 2, st4 = slab_stride >> 2;
+    for (long q4 = (long)blockIdx.x * 256 + threadIdx.x; q4 < n4; q4 += (long)gridDim.x * 256) {
+        const float4* src = (const float4*)slab + q4;
+        float4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = k < nsplit ? src[(long)k * st4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float s[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float* f = (const float*)v + e;
+            s[e] = ((f[0] + f[4]) + (f[8] + f[12])) + ((f[16] + f[20]) + (f[24] + f[28]));
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned q = (unsigned)(q4 << 2) + e;       // n < 2^31 (checked by the launchers)
+            const unsigned d3 = mp.d3, d2 = mp.d2, d1 = mp.d1;
+            const unsigned i3 = q % d3;
+            unsigned t = q / d3;
+            const unsigned i2 = t % d2;
+            t /= d2;
+            const unsigned i1 = t % d1, i0 = t / d1;
+            if ((int)i0 < lim.l0 && (int)i1 < lim.l1 && (int)i2 < lim.l2 && (int)i3 < lim.l3) {
+                const long dst = mp.base + i0 * mp.s0 + i1 * mp.s1 + i2 * mp.s2 + i3 * mp.s3;
+                out[dst] = accumulate ? out[dst] + s[e] : s[e];
+            }
+        }
+    }
+}
+
+int g_reduce_direct_mode = 1;
+// 0: four split groups x 64 columns, 1: sixteen x 16, 2: the direct form
+static inline int reduce_form(int nsplit) { return nsplit >= 64 ? 1 : (g_reduce_direct_mode && nsplit <= 8) ? 2 : 0; }
+static inline long reduce_cols(int form) { return form == 1 ? 16 : form == 2 ? 256 : 64; }
 
 __global__ __launch_bounds__(256) void reduce_slabs_scatter_kernel(const float* __restrict__ slab, int nsplit,
                                                                    long slab_stride, float* __restrict__ out, long n,
                                                                    IndexMap mp, Limits lim, int accumulate, int sg16) {
     __shared__ float4 red[256];
-    if (sg16) reduce_slabs_scatter_body<16>(slab, nsplit, slab_stride, out, n, mp, lim, accumulate, red);
+    if (sg16 == 2) reduce_slabs_direct_body(slab, nsplit, slab_stride, out, n, mp, lim, accumulate);
+    else if (sg16) reduce_slabs_scatter_body<16>(slab, nsplit, slab_stride, out, n, mp, lim, accumulate, red);
     else reduce_slabs_scatter_body<4>(slab, nsplit, slab_stride, out, n, mp, lim, accumulate, red);
 }
 
@@ -340,7 +379,7 @@ struct ReduceJob {
     long slab_stride, n;
     IndexMap mp;
     Limits lim;
-    int nsplit, accumulate, sg16;
+    int nsplit, accumulate, sg16;      // sg16: the form (see reduce_form)
 };
 struct ReduceJobs {
     ReduceJob j[VAE_MAX_REDUCE_JOBS];
@@ -348,8 +387,9 @@ struct ReduceJobs {
 __global__ __launch_bounds__(256) void multi_reduce_slabs_scatter_kernel(const ReduceJobs jobs) {
     __shared__ float4 red[256];
     const ReduceJob& jb = jobs.j[blockIdx.y];
-    if ((long)blockIdx.x * (jb.sg16 ? 16 : 64) >= (jb.n >> 2)) return;      // whole workgroup: no barrier is skipped by part of it
-    if (jb.sg16) reduce_slabs_scatter_body<16>(jb.slab, jb.nsplit, jb.slab_stride, jb.out, jb.n, jb.mp, jb.lim, jb.accumulate, red);
+    if ((long)blockIdx.x * (jb.sg16 == 2 ? 256 : jb.sg16 ? 16 : 64) >= (jb.n >> 2)) return;      // whole workgroup: no barrier is skipped by part of it
+    if (jb.sg16 == 2) reduce_slabs_direct_body(jb.slab, jb.nsplit, jb.slab_stride, jb.out, jb.n, jb.mp, jb.lim, jb.accumulate);
+    else if (jb.sg16) reduce_slabs_scatter_body<16>(jb.slab, jb.nsplit, jb.slab_stride, jb.out, jb.n, jb.mp, jb.lim, jb.accumulate, red);
     else reduce_slabs_scatter_body<4>(jb.slab, jb.nsplit, jb.slab_stride, jb.out, jb.n, jb.mp, jb.lim, jb.accumulate, red);
 }
 
@@ -674,8 +714,9 @@ extern "C" int vae_reduce_slabs_scatter(const float* slab, int nsplit, long slab
     const long n = dims4[0] * dims4[1] * dims4[2] * dims4[3];
     VAE_CHECK(n % 4 == 0 && slab_stride % 4 == 0 && slab_base % 4 == 0 && ((uintptr_t)slab & 15) == 0,
               "vae_reduce_slabs_scatter: element count, slab stride and base must be multiples of 4 (16-byte rows)");
-    const int sg16 = reduce_wide_groups(nsplit);
-    const long cw = sg16 ? 16 : 64, blocks = (n / 4 + cw - 1) / cw;
+    VAE_CHECK(n < (1L << 31), "vae_reduce_slabs_scatter: more than 2^31 elements");
+    const int sg16 = reduce_form(nsplit);
+    const long cw = reduce_cols(sg16), blocks = (n / 4 + cw - 1) / cw;
     const int grid = (int)(blocks > 2048 ? 2048 : blocks);
     ProfScope prof("reduce_slabs_scatter_kernel", 0.0, 4.0 * n * (nsplit + 1), (hipStream_t)stream);
     hipLaunchKernelGGL(reduce_slabs_scatter_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, slab + slab_base,
@@ -700,8 +741,9 @@ extern "C" int vae_multi_reduce_slabs_scatter(const vae_reduce_job* jobs, int nj
                   "vae_multi_reduce_slabs_scatter: job %d: element count, slab stride and base must be multiples of 4", i);
         rj.j[i].slab = q.slab + q.slab_base; rj.j[i].out = q.out; rj.j[i].slab_stride = q.slab_stride; rj.j[i].n = n;
         rj.j[i].nsplit = q.nsplit; rj.j[i].accumulate = q.accumulate;
-        rj.j[i].sg16 = reduce_wide_groups(q.nsplit);
-        const long cw = rj.j[i].sg16 ? 16 : 64;
+        VAE_CHECK(n < (1L << 31), "vae_multi_reduce_slabs_scatter: job %d has more than 2^31 elements", i);
+        rj.j[i].sg16 = reduce_form(q.nsplit);
+        const long cw = reduce_cols(rj.j[i].sg16);
         const long blocks = (n / 4 + cw - 1) / cw;
         if (blocks > max_blocks) max_blocks = blocks;
         bytes += 4.0 * n * (q.nsplit + 1);
