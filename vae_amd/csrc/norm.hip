@@ -441,35 +441,47 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const bf16_t* __restrict_
     for (int o = 0; o < CO; ++o) load8f(w + o * 64 + c0, wv[o]);
     const long stride = (long)gridDim.x * (blockDim.x >> 3);
     const long iters = (npix + stride - 1) / stride;
-    for (long it = 0; it < iters; ++it) {
-        const long pix = it * stride + (long)blockIdx.x * (blockDim.x >> 3) + (threadIdx.x >> 3);
-        const bool ok = pix < npix;
-        float v[8], acc[CO];
+    // HU pixels per lane and round: their loads are all in flight before any is used
+    constexpr int HU = 4;
+    for (long it = 0; it < iters; it += HU) {
+        long pix[HU];
+        bool ok[HU];
+        uint4 raw[HU];
 #pragma unroll
-        for (int o = 0; o < CO; ++o) acc[o] = 0.f;
-        if (ok) {
-            load8(y + pix * 64 + c0, v);      // plain: the backward pass re-reads y a few kernels later, from cache
+        for (int u = 0; u < HU; ++u) {
+            pix[u] = (it + u) * stride + (long)blockIdx.x * (blockDim.x >> 3) + (threadIdx.x >> 3);
+            ok[u] = pix[u] < npix;
+            raw[u] = make_uint4(0u, 0u, 0u, 0u);
+            if (ok[u]) raw[u] = *(const uint4*)(y + pix[u] * 64 + c0);      // plain: the backward pass re-reads y a few kernels later, from cache
+        }
+#pragma unroll
+        for (int u = 0; u < HU; ++u) {
+            float acc[CO];
+#pragma unroll
+            for (int o = 0; o < CO; ++o) acc[o] = 0.f;
+            const uint32_t wd[4] = {raw[u].x, raw[u].y, raw[u].z, raw[u].w};
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const float a = fmaxf(v[i] * sc[i] + sh[i], 0.f);
+                const float vi = __uint_as_float((i & 1) ? (wd[i >> 1] & 0xFFFF0000u) : (wd[i >> 1] << 16));
+                const float a = fmaxf(vi * sc[i] + sh[i], 0.f);
 #pragma unroll
                 for (int o = 0; o < CO; ++o) acc[o] += a * wv[o][i];
             }
-        }
 #pragma unroll
-        for (int o = 0; o < CO; ++o) {
-            acc[o] += __shfl_xor(acc[o], 1, 64);
-            acc[o] += __shfl_xor(acc[o], 2, 64);
-            acc[o] += __shfl_xor(acc[o], 4, 64);
-        }
-        if (ok && sub < CO) {
-            float l = 0.f;
+            for (int o = 0; o < CO; ++o) {
+                acc[o] += __shfl_xor(acc[o], 1, 64);
+                acc[o] += __shfl_xor(acc[o], 2, 64);
+                acc[o] += __shfl_xor(acc[o], 4, 64);
+            }
+            if (ok[u] && sub < CO) {
+                float l = 0.f;
 #pragma unroll
-            for (int o = 0; o < CO; ++o) if (sub == o) l = acc[o] + b[o];
-            // npix < 2^31: 32-bit index math, shifts when the image is a power of two
-            const unsigned up = (unsigned)pix;
-            const unsigned img = hwshift >= 0 ? up >> hwshift : up / (unsigned)hw, p = up - img * (unsigned)hw;
-            recon[((long)img * CO + sub) * hw + p] = 1.f / (1.f + expf(-l));
+                for (int o = 0; o < CO; ++o) if (sub == o) l = acc[o] + b[o];
+                // npix < 2^31: 32-bit index math, shifts when the image is a power of two
+                const unsigned up = (unsigned)pix[u];
+                const unsigned img = hwshift >= 0 ? up >> hwshift : up / (unsigned)hw, p = up - img * (unsigned)hw;
+                recon[((long)img * CO + sub) * hw + p] = 1.f / (1.f + expf(-l));
+            }
         }
     }
 }
