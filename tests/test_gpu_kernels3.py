@@ -121,6 +121,34 @@ def test_multi_reduce_equals_the_single_folds(L):
         L.call("vae_multi_reduce_slabs_scatter", jobs, 2, L.current_stream())
 
 
+@pytest.mark.parametrize("S,Co,T,Ci", [(1, 8, 9, 16), (2, 256, 9, 256), (5, 64, 4, 128), (8, 64, 9, 64), (2, 1024, 9, 272)])
+def test_fold_of_few_slabs_in_both_forms(L, S, Co, T, Ci):
+    """slab folds of at most 8 slabs take a form of their own (one thread per 16-byte column, no barrier): same sums
+    as the split-group form up to the order of the additions, same scatter, same accumulate; the last case is larger
+    than one round of the capped grid"""
+    g = torch.Generator().manual_seed(5)
+    slab = torch.randn(S, Co, T, Ci, generator=g).to(DEV)
+    ref = slab.double().sum(0).permute(0, 2, 1).float()          # [co][ci][tap]
+    outs = []
+    try:
+        for form in (1, 0):
+            L.call("vae_set_tuning", b"reduce_direct", form)
+            out = torch.ones(Co, Ci, T, device=DEV)
+            L.call("vae_reduce_slabs_scatter", L.ptr(slab), S, Co * T * Ci, 0, L.ptr(out), L.long4(Co, T, Ci, 1),
+                   L.long4(T * Ci, 1, T, 0), None, 0, 0, L.current_stream())
+            assert rel_l2(out.cpu(), ref.cpu()) <= 1e-6
+            acc = torch.ones(Co, Ci, T, device=DEV)
+            L.call("vae_reduce_slabs_scatter", L.ptr(slab), S, Co * T * Ci, 0, L.ptr(acc), L.long4(Co, T, Ci, 1),
+                   L.long4(T * Ci, 1, T, 0), None, 0, 1, L.current_stream())
+            assert rel_l2(acc.cpu(), (ref + 1.0).cpu()) <= 1e-6
+            outs.append(out)
+    finally:
+        L.call("vae_set_tuning", b"reduce_direct", 1)
+    assert rel_l2(outs[0].cpu(), outs[1].cpu()) <= 1e-6
+    if S <= 2:
+        assert torch.equal(outs[0], outs[1])        # one addition per element: no order to differ in
+
+
 @pytest.mark.parametrize("n", [4096 * 997 + 3, 1000])
 def test_adamw_clip_step_matches_oracle(L, n):
     g = torch.Generator().manual_seed(n)
