@@ -749,6 +749,11 @@ extern "C" int vae_multi_reduce_slabs_scatter(const vae_reduce_job* jobs, int nj
         bytes += 4.0 * n * (q.nsplit + 1);
     }
     if (max_blocks > 2048) max_blocks = 2048;
+    // Workgroups are dispatched job by job: the jobs with the most slabs -- whose threads walk the longest chains of
+    // dependent round trips -- go first, so that their tails run beside the wide, short jobs instead of after them.
+    // (The jobs are independent: the order changes no result.)
+    for (int i = 1; i < njobs; ++i)
+        for (int k = i; k > 0 && rj.j[k].nsplit > rj.j[k - 1].nsplit; --k) { const ReduceJob t = rj.j[k]; rj.j[k] = rj.j[k - 1]; rj.j[k - 1] = t; }
     ProfScope prof("reduce_slabs_scatter_kernel", 0.0, bytes, (hipStream_t)stream);
     hipLaunchKernelGGL(multi_reduce_slabs_scatter_kernel, dim3((int)max_blocks, njobs), dim3(256), 0, (hipStream_t)stream, rj);
     VAE_LAUNCH_CHECK("multi_reduce_slabs_scatter_kernel");
