@@ -810,6 +810,9 @@ extern "C" int vae_multi_pack(const vae_pack_job* jobs, int njobs, void* stream)
         if (items > max_items) max_items = items;
         bytes += n * (jobs[i].f32 ? 8.0 : 6.0);
     }
+    // the largest jobs are dispatched first (the jobs are independent: their order changes no result)
+    for (int i = 1; i < njobs; ++i)
+        for (int k = i; k > 0 && pj.j[k].n > pj.j[k - 1].n; --k) { const PackJob t = pj.j[k]; pj.j[k] = pj.j[k - 1]; pj.j[k - 1] = t; }
     int gx = (max_items + 255) / 256;
     if (gx > 1024) gx = 1024;
     if (gx > 8) gx &= ~7;          // whole rounds of the 8 XCDs (the kernel then keeps each XCD on its own part of a job)
